@@ -1,0 +1,435 @@
+"""CPU oracle for the MAE pre-training hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch (CPU, fp32, no MONAI/timm/yacs) restatement of the
+reference algorithm for one MAE pre-training step.  It is NOT part of the
+product: only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` may import it.  The product path
+(``headct_foundation_amd``) never imports anything from ``oracle/``.
+
+Parity pin: the reference has no tests or golden vectors of its own
+(SURVEY.md section 4).  The oracle is pinned against outputs of the reference
+itself, generated in the build container by ``tests/golden/make_golden.py``
+(which imports the reference's own ``src/models/mae.py`` etc. with stand-ins
+for the seven absent MONAI/timm symbols) and committed under ``tests/golden``.
+
+Every function cites the reference file:line it follows (paths relative to
+the reference root).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------
+# configuration
+# ----------------------------------------------------------------------------
+@dataclass
+class MAEConfig:
+    """Constructor surface of MaskedAutoencoderViT (src/models/mae.py:22-42)."""
+    input_size: int = 96
+    patch_size: int = 16
+    mask_ratio: float = 0.75
+    in_chans: int = 1
+    pos_embed: str = "sincos"
+    encoder_depth: int = 12
+    encoder_embed_dim: int = 768
+    encoder_mlp_dim: int = 3072
+    encoder_num_heads: int = 12
+    decoder_depth: int = 8
+    decoder_embed_dim: int = 768
+    decoder_mlp_dim: int = 3072
+    decoder_num_heads: int = 16
+    norm_pix_loss: bool = False
+    use_bias: bool = False
+
+    @property
+    def grid(self) -> int:
+        return self.input_size // self.patch_size
+
+    @property
+    def num_patches(self) -> int:  # L
+        return self.grid ** 3
+
+    @property
+    def patch_dim(self) -> int:  # pd = C * P^3
+        return self.in_chans * self.patch_size ** 3
+
+    @property
+    def len_keep(self) -> int:  # mae.py:205
+        return int(self.num_patches * (1 - self.mask_ratio))
+
+    def ctor_kwargs(self) -> dict:
+        return dict(
+            input_size=self.input_size, patch_size=self.patch_size, mask_ratio=self.mask_ratio,
+            in_chans=self.in_chans, dropout_rate=0.0, spatial_dims=3, patch_embed="conv",
+            pos_embed=self.pos_embed, encoder_depth=self.encoder_depth,
+            encoder_embed_dim=self.encoder_embed_dim, encoder_mlp_dim=self.encoder_mlp_dim,
+            encoder_num_heads=self.encoder_num_heads, decoder_depth=self.decoder_depth,
+            decoder_embed_dim=self.decoder_embed_dim, decoder_mlp_dim=self.decoder_mlp_dim,
+            decoder_num_heads=self.decoder_num_heads, norm_pix_loss=self.norm_pix_loss,
+            use_bias=self.use_bias)
+
+
+# Named configurations used by tests / bench (BASELINE.json configs).
+CONFIGS: Dict[str, MAEConfig] = {
+    # tiny full-tensor fixture case (not in BASELINE; small enough to commit whole)
+    "micro": MAEConfig(input_size=32, patch_size=8, encoder_depth=2, encoder_embed_dim=48,
+                       encoder_mlp_dim=96, encoder_num_heads=3, decoder_depth=1,
+                       decoder_embed_dim=48, decoder_mlp_dim=96, decoder_num_heads=3,
+                       use_bias=True, in_chans=1),
+    # BASELINE config #1: ViT-Tiny, 2-layer decoder, 64^3, patch 16
+    "tiny": MAEConfig(input_size=64, patch_size=16, encoder_depth=12, encoder_embed_dim=192,
+                      encoder_mlp_dim=768, encoder_num_heads=3, decoder_depth=2,
+                      decoder_embed_dim=192, decoder_mlp_dim=768, decoder_num_heads=3),
+    # cut-down config #2: real ViT-B tile shapes (N=55/217, dh=64/48), depth 1+1
+    "vitb_cut": MAEConfig(input_size=96, patch_size=16, encoder_depth=1, decoder_depth=1),
+    # BASELINE config #2/#3: ViT-B/16^3, 96^3
+    "vitb": MAEConfig(input_size=96, patch_size=16),
+    # BASELINE config #4: ViT-L, 128^3, learnable pos-embed (1024 % 6 != 0, pos_embed.py:60)
+    "vitl": MAEConfig(input_size=128, patch_size=16, pos_embed="learnable", encoder_depth=24,
+                      encoder_embed_dim=1024, encoder_mlp_dim=4096, encoder_num_heads=16),
+    # multi-channel / patch-12 shape of the shipped yaml (configs/mae/mae_HeadCT.yaml:31-50), cut down
+    "yaml_cut": MAEConfig(input_size=48, patch_size=12, in_chans=3, encoder_depth=1,
+                          encoder_embed_dim=96, encoder_mlp_dim=192, encoder_num_heads=3,
+                          decoder_depth=1, decoder_embed_dim=96, decoder_mlp_dim=192,
+                          decoder_num_heads=2, use_bias=True, norm_pix_loss=True),
+}
+
+
+# ----------------------------------------------------------------------------
+# parameters: names / shapes (probe-dumped from the reference)
+# ----------------------------------------------------------------------------
+def param_shapes(cfg: MAEConfig) -> List[Tuple[str, Tuple[int, ...], bool]]:
+    """(name, shape, requires_grad) in the reference's registration order
+    (src/models/mae.py:86-121, attentionblock.py:91-94, MONAI MLPBlock linear1/linear2)."""
+    D, Dd = cfg.encoder_embed_dim, cfg.decoder_embed_dim
+    L, P, C = cfg.num_patches, cfg.patch_size, cfg.in_chans
+    out: List[Tuple[str, Tuple[int, ...], bool]] = [
+        ("cls_token", (1, 1, D), True),
+        ("decoder_cls_token", (1, 1, Dd), True),
+        ("decoder_pos_embed", (1, L, Dd), False),  # mae.py:92 requires_grad=False
+        ("mask_token", (1, 1, Dd), True),
+    ]
+    if cfg.pos_embed != "none":
+        out.append(("patch_embedding.position_embeddings", (1, L, D), True))
+    out += [
+        ("patch_embedding.patch_embeddings.weight", (D, C, P, P, P), True),
+        ("patch_embedding.patch_embeddings.bias", (D,), True),
+    ]
+
+    def block(prefix: str, d: int, m: int):
+        r = [
+            (f"{prefix}.mlp.linear1.weight", (m, d), True),
+            (f"{prefix}.mlp.linear1.bias", (m,), True),
+            (f"{prefix}.mlp.linear2.weight", (d, m), True),
+            (f"{prefix}.mlp.linear2.bias", (d,), True),
+            (f"{prefix}.att_norm.weight", (d,), True),
+            (f"{prefix}.att_norm.bias", (d,), True),
+            (f"{prefix}.ffn_norm.weight", (d,), True),
+            (f"{prefix}.ffn_norm.bias", (d,), True),
+            (f"{prefix}.attn.qkv.weight", (3 * d, d), True),
+        ]
+        if cfg.use_bias:
+            r.append((f"{prefix}.attn.qkv.bias", (3 * d,), True))
+        r += [
+            (f"{prefix}.attn.proj.weight", (d, d), True),
+            (f"{prefix}.attn.proj.bias", (d,), True),
+        ]
+        return r
+
+    for i in range(cfg.encoder_depth):
+        out += block(f"blocks.{i}", D, cfg.encoder_mlp_dim)
+    for i in range(cfg.decoder_depth):
+        out += block(f"decoder_blocks.{i}", Dd, cfg.decoder_mlp_dim)
+    out += [("norm.weight", (D,), True), ("norm.bias", (D,), True),
+            ("decoder_norm.weight", (Dd,), True), ("decoder_norm.bias", (Dd,), True),
+            ("decoder_embed.weight", (Dd, D), True)]
+    if cfg.use_bias:
+        out.append(("decoder_embed.bias", (Dd,), True))
+    out.append(("decoder_pred.weight", (cfg.patch_dim, Dd), True))
+    if cfg.use_bias:
+        out.append(("decoder_pred.bias", (cfg.patch_dim,), True))
+    return out
+
+
+def build_sincos_position_embedding_3d(grid: int, embed_dim: int, temperature: float = 10000.0) -> torch.Tensor:
+    """src/utils/pos_embed.py:51-78 (3-D branch; cubic grid so the h/w naming swap :54-55 is moot)."""
+    assert embed_dim % 6 == 0, "Embed dimension must be divisible by 6 for 3D sin-cos position embedding"
+    g = torch.arange(grid, dtype=torch.float32)
+    gh, gw, gd = torch.meshgrid(g, g, g, indexing="ij")
+    pos_dim = embed_dim // 6
+    omega = torch.arange(pos_dim, dtype=torch.float32) / pos_dim
+    omega = 1.0 / (temperature ** omega)
+    oh = torch.einsum("m,d->md", [gh.flatten(), omega])
+    ow = torch.einsum("m,d->md", [gw.flatten(), omega])
+    od = torch.einsum("m,d->md", [gd.flatten(), omega])
+    # reference concatenates (out_w, out_h, out_d) where out_h is built from the FIRST meshgrid
+    # output and out_w from the SECOND (pos_embed.py:58,65-76)
+    return torch.cat([torch.sin(ow), torch.cos(ow), torch.sin(oh), torch.cos(oh),
+                      torch.sin(od), torch.cos(od)], dim=1)[None]
+
+
+def hash_uniform(n: int, seed: int) -> np.ndarray:
+    """Portable deterministic U[-1,1) stream (integer hash; independent of any RNG library)."""
+    i = np.arange(n, dtype=np.uint64)
+    x = i + np.uint64((int(seed) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)  # wraps mod 2^64
+    x ^= x >> np.uint64(30)
+    x = (x * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    x ^= x >> np.uint64(27)
+    x = (x * np.uint64(0x94D049BB133111EB)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    x ^= x >> np.uint64(31)
+    u = (x >> np.uint64(40)).astype(np.float64) / float(1 << 24)  # 24-bit mantissa: exact in fp32
+    return (2.0 * u - 1.0).astype(np.float32)
+
+
+def make_params(cfg: MAEConfig, seed: int = 0, generic: bool = True) -> Dict[str, torch.Tensor]:
+    """Deterministic, library-independent parameters for parity fixtures.
+
+    generic=True perturbs biases / LayerNorm affine away from their (0, 1) init values so every
+    term of the forward/backward is exercised.  Scales follow the reference init
+    (mae.py:125-148: xavier-uniform linears, std .02 tokens; conv keeps kaiming-uniform default).
+    """
+    out: Dict[str, torch.Tensor] = {}
+    for k, (name, shape, _) in enumerate(param_shapes(cfg)):
+        n = int(np.prod(shape))
+        u = torch.from_numpy(hash_uniform(n, seed * 1000 + k + 1)).reshape(shape)
+        if name == "decoder_pos_embed" or name == "patch_embedding.position_embeddings":
+            if cfg.pos_embed == "sincos":
+                d = shape[-1]
+                t = build_sincos_position_embedding_3d(cfg.grid, d)
+                if name.startswith("patch") and generic:
+                    t = t + 0.02 * u  # trainable in the reference (patch_embedding.py:109,117-120)
+            else:
+                t = 0.02 * u
+        elif name.endswith("token"):
+            t = 0.02 * 1.7 * u
+        elif name.endswith("norm.weight"):
+            t = 1.0 + (0.1 * u if generic else 0.0 * u)
+        elif name.endswith("bias"):
+            t = 0.05 * u if generic else 0.0 * u
+            if name == "patch_embedding.patch_embeddings.bias":
+                t = u / math.sqrt(cfg.patch_dim)
+        elif name == "patch_embedding.patch_embeddings.weight":
+            t = u / math.sqrt(cfg.patch_dim)  # kaiming_uniform(a=sqrt(5)) bound = 1/sqrt(fan_in)
+        else:  # linear weight: xavier-uniform bound
+            fan_out, fan_in = shape
+            t = u * math.sqrt(6.0 / (fan_in + fan_out))
+        out[name] = t.contiguous().float()
+    return out
+
+
+def make_volume(cfg: MAEConfig, batch: int, seed: int = 0) -> torch.Tensor:
+    """Synthetic CT volume batch U[0,1) (windowed-CT value range, src/data/transforms.py:120-128)."""
+    S, C = cfg.input_size, cfg.in_chans
+    u = hash_uniform(batch * C * S * S * S, 7777 + seed)
+    return torch.from_numpy((u + 1.0) * 0.5).reshape(batch, C, S, S, S).contiguous()
+
+
+def make_noise(cfg: MAEConfig, batch: int, seed: int = 0) -> torch.Tensor:
+    """Tie-free masking noise in [0,1): a per-row permutation scaled to (0,1) (SURVEY 8a a5:
+    torch.argsort is unstable, so fixtures must not contain ties)."""
+    L = cfg.num_patches
+    u = hash_uniform(batch * L, 4242 + seed).reshape(batch, L)
+    order = np.argsort(u, axis=1, kind="stable")
+    rank = np.empty_like(order)
+    np.put_along_axis(rank, order, np.arange(L)[None, :].repeat(batch, 0), axis=1)
+    return torch.from_numpy(((rank.astype(np.float32) + 0.5) / L).astype(np.float32))
+
+
+# ----------------------------------------------------------------------------
+# forward (functional; parameters in a dict keyed by the reference's names)
+# ----------------------------------------------------------------------------
+def patchify(cfg: MAEConfig, x: torch.Tensor) -> torch.Tensor:
+    """src/models/mae.py:150-170: [B,C,H,W,D] -> [B, L, ph*pw*pd*C] (C fastest)."""
+    B, C = x.shape[:2]
+    g, p = cfg.grid, cfg.patch_size
+    x = x.reshape(B, C, g, p, g, p, g, p)
+    return x.permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(B, g ** 3, p ** 3 * C)
+
+
+def unpatchify(cfg: MAEConfig, x: torch.Tensor) -> torch.Tensor:
+    """src/models/mae.py:172-192 (inverse of patchify; "reconstructed voxels")."""
+    B = x.shape[0]
+    g, p, C = cfg.grid, cfg.patch_size, cfg.in_chans
+    x = x.reshape(B, g, g, g, p, p, p, C)
+    return x.permute(0, 7, 1, 4, 2, 5, 3, 6).reshape(B, C, g * p, g * p, g * p)
+
+
+def random_masking_from_noise(cfg: MAEConfig, noise: torch.Tensor):
+    """src/models/mae.py:204-216 with the noise supplied (stable argsort: ties -> lower index first)."""
+    K = cfg.len_keep
+    ids_shuffle = torch.argsort(noise, dim=1, stable=True)
+    ids_restore = torch.argsort(ids_shuffle, dim=1, stable=True)
+    ids_keep = ids_shuffle[:, :K]
+    mask = torch.ones(noise.shape, dtype=torch.float32)
+    mask[:, :K] = 0
+    mask = torch.gather(mask, 1, ids_restore)
+    return ids_shuffle, ids_restore, ids_keep, mask
+
+
+def _layer_norm(x, w, b):
+    return F.layer_norm(x, (x.shape[-1],), w, b, 1e-5)  # nn.LayerNorm default eps (attentionblock.py:92-93)
+
+
+def _block(p: Dict[str, torch.Tensor], prefix: str, h: torch.Tensor, heads: int, inter: Optional[dict], tag: str):
+    """AttentionBlock.forward attentionblock.py:96-99; SelfAttention.forward :51-66; MONAI MLPBlock (exact-erf GELU)."""
+    B, N, D = h.shape
+    x1 = _layer_norm(h, p[f"{prefix}.att_norm.weight"], p[f"{prefix}.att_norm.bias"])
+    qkv = F.linear(x1, p[f"{prefix}.attn.qkv.weight"], p.get(f"{prefix}.attn.qkv.bias"))
+    qkv = qkv.reshape(B, N, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    att = torch.softmax((q @ k.transpose(-1, -2)) * (D // heads) ** -0.5, dim=-1)  # SDPA, no mask, dropout 0 (:61)
+    y = (att @ v).transpose(1, 2).contiguous().view(B, N, D)
+    y = F.linear(y, p[f"{prefix}.attn.proj.weight"], p[f"{prefix}.attn.proj.bias"])
+    h = h + y
+    x2 = _layer_norm(h, p[f"{prefix}.ffn_norm.weight"], p[f"{prefix}.ffn_norm.bias"])
+    u = F.linear(x2, p[f"{prefix}.mlp.linear1.weight"], p[f"{prefix}.mlp.linear1.bias"])
+    gact = F.gelu(u)  # nn.GELU() default = exact erf
+    h = h + F.linear(gact, p[f"{prefix}.mlp.linear2.weight"], p[f"{prefix}.mlp.linear2.bias"])
+    if inter is not None:
+        inter[f"{tag}.out"] = h
+    return h
+
+
+def forward(cfg: MAEConfig, p: Dict[str, torch.Tensor], x: torch.Tensor, noise: torch.Tensor,
+            want_inter: bool = False):
+    """MaskedAutoencoderViT.forward src/models/mae.py:303-317.  Returns (loss, pred, mask, inter)."""
+    inter: Optional[dict] = {} if want_inter else None
+    B = x.shape[0]
+    D, Dd, L, K = cfg.encoder_embed_dim, cfg.decoder_embed_dim, cfg.num_patches, cfg.len_keep
+    P = cfg.patch_size
+    # --- forward_encoder mae.py:220-242 ---
+    # PatchEmbeddingBlock.forward patch_embedding.py:149-156: Conv3d(k=s=P) -> flatten(2).transpose -> + pos
+    tok = F.conv3d(x, p["patch_embedding.patch_embeddings.weight"], p["patch_embedding.patch_embeddings.bias"], stride=P)
+    tok = tok.flatten(2).transpose(-1, -2)
+    if "patch_embedding.position_embeddings" in p:
+        tok = tok + p["patch_embedding.position_embeddings"]
+    ids_shuffle, ids_restore, ids_keep, mask = random_masking_from_noise(cfg, noise)
+    xm = torch.gather(tok, 1, ids_keep.unsqueeze(-1).repeat(1, 1, D))  # mae.py:212
+    h = torch.cat((p["cls_token"].expand(B, -1, -1), xm), dim=1)  # mae.py:233-234
+    if inter is not None:
+        inter.update(patch_embed=tok, ids_restore=ids_restore, ids_keep=ids_keep, mask=mask, enc_in=h)
+    for i in range(cfg.encoder_depth):
+        h = _block(p, f"blocks.{i}", h, cfg.encoder_num_heads, inter, f"enc{i}")
+    latent = _layer_norm(h, p["norm.weight"], p["norm.bias"])  # mae.py:240
+    # --- forward_decoder mae.py:244-275 ---
+    y = F.linear(latent, p["decoder_embed.weight"], p.get("decoder_embed.bias"))
+    mask_tokens = p["mask_token"].repeat(B, L + 1 - y.shape[1], 1)
+    y_ = torch.cat([y[:, 1:, :], mask_tokens], dim=1)
+    y_ = torch.gather(y_, 1, ids_restore.unsqueeze(-1).repeat(1, 1, Dd))
+    y = torch.cat([y[:, :1, :], y_], dim=1)
+    dpe = torch.cat((p["decoder_cls_token"].expand(B, -1, -1), p["decoder_pos_embed"].expand(B, -1, -1)), dim=1)
+    y = y + dpe  # decoder_cls_token is ADDED to position 0 (mae.py:262-265)
+    if inter is not None:
+        inter.update(latent=latent, dec_in=y)
+    for i in range(cfg.decoder_depth):
+        y = _block(p, f"decoder_blocks.{i}", y, cfg.decoder_num_heads, inter, f"dec{i}")
+    y = _layer_norm(y, p["decoder_norm.weight"], p["decoder_norm.bias"])
+    pred = F.linear(y, p["decoder_pred.weight"], p.get("decoder_pred.bias"))[:, 1:, :]
+    # --- forward_loss mae.py:277-301 ---
+    target = patchify(cfg, x)
+    if cfg.norm_pix_loss:
+        mean = target.mean(dim=-1, keepdim=True)
+        var = target.var(dim=-1, keepdim=True)  # unbiased (mae.py:292)
+        target = (target - mean) / (var + 1.0e-6) ** 0.5
+    loss = ((pred - target) ** 2).mean(dim=-1)
+    loss = (loss * mask).sum() / mask.sum()
+    if inter is not None:
+        inter.update(pred=pred, target=target)
+    return loss, pred, mask, inter
+
+
+def forward_backward(cfg: MAEConfig, params: Dict[str, torch.Tensor], x: torch.Tensor, noise: torch.Tensor,
+                     want_inter: bool = False):
+    """loss + autograd gradients of every trainable parameter (engine_pretrain_mae.py:58-62, AMP off)."""
+    frozen = {n for n, _, rg in param_shapes(cfg) if not rg}
+    p = {k: (v.clone().requires_grad_(k not in frozen)) for k, v in params.items()}
+    loss, pred, mask, inter = forward(cfg, p, x, noise, want_inter)
+    loss.backward()
+    grads = {k: v.grad for k, v in p.items() if v.grad is not None}
+    return loss.detach(), pred.detach(), mask, grads, ({k: v.detach() for k, v in inter.items()} if inter else None)
+
+
+# ----------------------------------------------------------------------------
+# optimizer step: per-parameter clip + AdamW + cosine-warmup LR
+# ----------------------------------------------------------------------------
+def clip_gradients_(grads: Dict[str, torch.Tensor], clip: float) -> Dict[str, float]:
+    """src/utils/misc.py:374-383: PER-TENSOR L2 clip, coef = clip/(norm+1e-6), applied iff coef < 1."""
+    norms = {}
+    for k, g in grads.items():
+        n = g.norm(2)
+        norms[k] = float(n)
+        coef = clip / (n + 1e-6)
+        if coef < 1:
+            g.mul_(coef)
+    return norms
+
+
+def cosine_warmup_lambda(step: int, warmup: int, total: int, lr_init: float, lr_end: float) -> float:
+    """src/utils/lr_sched.py:46-53 (num_cycles = 0.5)."""
+    if step < warmup:
+        return float(step) / float(max(1, warmup))
+    lr_range = lr_init - lr_end
+    progress = float(step - warmup) / float(max(1, total - warmup))
+    lr_new = lr_end + lr_range * 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * progress))
+    return max(0.0, lr_new / lr_init)
+
+
+def adamw_step_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,
+                beta1: float, beta2: float, eps: float, wd: float) -> None:
+    """torch.optim.AdamW single-tensor math (optimizers.py:354-360 -> torch defaults eps=1e-8,
+    decoupled weight decay on EVERY parameter, one param group).  `step` is 1-based."""
+    p.mul_(1.0 - lr * wd)
+    m.mul_(beta1).add_(g, alpha=1.0 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+@dataclass
+class TrainState:
+    params: Dict[str, torch.Tensor]
+    exp_avg: Dict[str, torch.Tensor] = field(default_factory=dict)
+    exp_avg_sq: Dict[str, torch.Tensor] = field(default_factory=dict)
+    step: int = 0  # optimizer steps taken == scheduler steps taken
+
+
+def train_step(cfg: MAEConfig, st: TrainState, x: torch.Tensor, noise: torch.Tensor, *, base_lr: float,
+               min_lr: float, warmup: int, total: int, weight_decay: float, beta1: float = 0.9,
+               beta2: float = 0.95, grad_clip: float = 0.0):
+    """One iteration of train_one_epoch (engine_pretrain_mae.py:52-71), AMP disabled:
+    zero_grad -> forward -> backward -> per-param clip -> AdamW(lr_t) -> scheduler.step()."""
+    loss, pred, mask, grads, _ = forward_backward(cfg, st.params, x, noise)
+    norms = clip_gradients_(grads, grad_clip) if grad_clip else {}
+    lr = base_lr * cosine_warmup_lambda(st.step, warmup, total, base_lr, min_lr)  # LambdaLR: lr at step index
+    st.step += 1
+    with torch.no_grad():
+        for k, g in grads.items():
+            if k not in st.exp_avg:
+                st.exp_avg[k] = torch.zeros_like(g)
+                st.exp_avg_sq[k] = torch.zeros_like(g)
+            adamw_step_(st.params[k], g, st.exp_avg[k], st.exp_avg_sq[k], st.step, lr, beta1, beta2, 1e-8, weight_decay)
+    return float(loss), lr, grads, norms
+
+
+# ----------------------------------------------------------------------------
+# algorithmic FLOPs
+# ----------------------------------------------------------------------------
+def algorithmic_flops_per_volume(cfg: MAEConfig) -> Dict[str, float]:
+    D, M, Dd, Md = cfg.encoder_embed_dim, cfg.encoder_mlp_dim, cfg.decoder_embed_dim, cfg.decoder_mlp_dim
+    L, K, pd = cfg.num_patches, cfg.len_keep, cfg.patch_dim
+    Ne, Nd = K + 1, L + 1
+    blk = lambda N, d, m: N * (8 * d * d + 4 * d * m) + 4 * N * N * d
+    out = dict(pe=2.0 * K * pd * D, enc=float(cfg.encoder_depth * blk(Ne, D, M)), dec_embed=2.0 * Ne * D * Dd,
+               dec=float(cfg.decoder_depth * blk(Nd, Dd, Md)), pred=2.0 * L * Dd * pd)
+    out["fwd"] = sum(out.values())
+    out["train"] = 3.0 * out["fwd"]
+    return out

@@ -1,0 +1,298 @@
+"""Generate golden fixtures from the REFERENCE itself (build container only).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Imports the reference's own src/models/mae.py, attentionblock.py, patch_embedding.py,
+pos_embed.py, misc.py, lr_sched.py and engine_pretrain_mae.py from /root/reference,
+with stand-ins registered in sys.modules for the seven third-party symbols that are
+absent from this image (timm to_2tuple/to_3tuple; MONAI Conv,
+trunc_normal_, MLPBlock, ensure_tuple_rep, optional_import, look_up_option).
+Nothing of the reference's text is stored: fixtures hold inputs-by-seed and outputs
+(loss, sampled activations/gradients/parameters, LR values, loss curve, key manifest).
+
+Inputs and weights are NOT stored: they come from oracle.mae_oracle.make_params /
+make_volume / make_noise, a portable integer-hash stream, so the GPU box regenerates
+them bit-exactly.
+"""
+import importlib.machinery
+import json
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from oracle import mae_oracle as O  # noqa: E402
+
+
+def _mod(name):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+def install_standins():
+    def _ntuple(n):
+        def f(x):
+            if isinstance(x, (list, tuple)):
+                return tuple(x)
+            return tuple([x] * n)
+        return f
+
+    timm = _mod("timm"); tm = _mod("timm.models"); tl = _mod("timm.models.layers")
+    tl.to_2tuple, tl.to_3tuple = _ntuple(2), _ntuple(3)
+    timm.models = tm; tm.layers = tl
+
+    monai = _mod("monai"); mn = _mod("monai.networks"); ml = _mod("monai.networks.layers")
+    mb = _mod("monai.networks.blocks"); mm = _mod("monai.networks.blocks.mlp")
+    mu = _mod("monai.utils"); mum = _mod("monai.utils.module")
+
+    class _Conv:
+        CONV = "conv"
+        def __getitem__(self, key):
+            kind, dims = key
+            assert kind == "conv" and dims == 3
+            return nn.Conv3d
+    ml.Conv = _Conv()
+
+    def trunc_normal_(t, mean=0.0, std=1.0, a=-2.0, b=2.0):
+        with torch.no_grad():
+            return nn.init.trunc_normal_(t, mean=mean, std=std, a=a, b=b)
+    ml.trunc_normal_ = trunc_normal_
+
+    class MLPBlock(nn.Module):  # MONAI 1.2/1.3 MLPBlock semantics
+        def __init__(self, hidden_size, mlp_dim, dropout_rate=0.0):
+            super().__init__()
+            self.linear1 = nn.Linear(hidden_size, mlp_dim)
+            self.linear2 = nn.Linear(mlp_dim, hidden_size)
+            self.fn = nn.GELU()
+            self.drop1 = nn.Dropout(dropout_rate)
+            self.drop2 = nn.Dropout(dropout_rate)
+        def forward(self, x):
+            return self.drop2(self.linear2(self.drop1(self.fn(self.linear1(x)))))
+    mm.MLPBlock = MLPBlock
+
+    def ensure_tuple_rep(x, n):
+        return tuple(x) if isinstance(x, (list, tuple)) else tuple([x] * n)
+    def optional_import(module, name=""):
+        try:
+            m = __import__(module, fromlist=[name] if name else [])
+            return (getattr(m, name) if name else m), True
+        except Exception:
+            return None, False
+    def look_up_option(opt, supported):
+        if opt not in supported:
+            raise ValueError(f"unsupported option {opt}")
+        return opt
+    mu.ensure_tuple_rep = ensure_tuple_rep
+    mu.optional_import = optional_import
+    mum.look_up_option = look_up_option
+    monai.networks = mn; mn.layers = ml; mn.blocks = mb; mb.mlp = mm; monai.utils = mu; mu.module = mum
+
+
+def sample(t: torch.Tensor, n: int = 192):
+    """Strided sample + norms of a tensor (keeps fixtures small)."""
+    f = t.detach().double().flatten()
+    idx = np.unique(np.linspace(0, f.numel() - 1, min(n, f.numel())).astype(np.int64))
+    return dict(shape=list(t.shape), idx=idx.tolist(), val=f[idx].tolist(), l2=float(f.norm()), sum=float(f.sum()))
+
+
+TRAIN_HP = dict(base_lr=1.5e-4 * 2 / 256 * 64, min_lr=1.5e-7, warmup=2, total=8, weight_decay=5e-3,
+                beta1=0.9, beta2=0.95, grad_clip=3.0)
+
+
+def build_reference_model(cfg: O.MAEConfig, params):
+    from src.models.mae import MaskedAutoencoderViT
+    m = MaskedAutoencoderViT(**cfg.ctor_kwargs())
+    sd = m.state_dict()
+    names = [n for n, _, _ in O.param_shapes(cfg)]
+    assert list(sd.keys()) == names, (list(sd.keys())[:12], names[:12])
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(params[k].shape), k
+    m.load_state_dict(params, strict=True)
+    return m
+
+
+def run_case(name: str, batch: int, seed: int, full: bool):
+    cfg = O.CONFIGS[name]
+    params = O.make_params(cfg, seed)
+    x = O.make_volume(cfg, batch, seed)
+    noise = O.make_noise(cfg, batch, seed)
+    model = build_reference_model(cfg, params)
+    model.train()
+
+    # The reference draws noise with torch.rand(N, L) as the only RNG draw of forward (mae.py:206).
+    # Inject our tie-free noise by patching torch.rand for the duration of the call.
+    real_rand = torch.rand
+    def fake_rand(*a, **k):
+        assert tuple(a) == tuple(noise.shape), a
+        return noise.clone()
+    captured = {}
+    hooks = []
+    def cap(tag):
+        def h(mod, inp, out):
+            captured[tag] = (out[0] if isinstance(out, tuple) else out).detach()
+        return h
+    hooks.append(model.patch_embedding.register_forward_hook(cap("patch_embed")))
+    for i, b in enumerate(model.blocks):
+        hooks.append(b.register_forward_hook(cap(f"enc{i}.out")))
+    for i, b in enumerate(model.decoder_blocks):
+        hooks.append(b.register_forward_hook(cap(f"dec{i}.out")))
+    hooks.append(model.norm.register_forward_hook(cap("latent")))
+    hooks.append(model.decoder_pred.register_forward_hook(cap("pred_full")))
+    torch.rand = fake_rand
+    try:
+        loss, _, _ = model(x)
+    finally:
+        torch.rand = real_rand
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    pred = captured["pred_full"][:, 1:, :]
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    # ---- oracle vs reference (same inputs) ----
+    o_loss, o_pred, o_mask, o_grads, o_inter = O.forward_backward(cfg, params, x, noise, want_inter=True)
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    rep = {"loss": abs(float(o_loss) - float(loss.detach())) / abs(float(loss.detach())), "pred": rel(o_pred, pred)}
+    for k in ("patch_embed", "latent"):
+        rep[k] = rel(o_inter[k], captured[k])
+    for k in captured:
+        if k.endswith(".out"):
+            rep[k] = rel(o_inter[k], captured[k])
+    assert set(o_grads) == set(grads), set(o_grads) ^ set(grads)
+    rep["grad_max"] = max(rel(o_grads[k], grads[k]) for k in grads)
+    print(f"[{name}] oracle-vs-reference rel err:", {k: f"{v:.2e}" for k, v in rep.items() if not k.endswith('.out')},
+          "blocks max", f"{max([v for k, v in rep.items() if k.endswith('.out')] or [0]):.2e}")
+    assert max(rep.values()) < 2e-5, rep
+
+    fx = dict(config=name, batch=batch, seed=seed, loss=float(loss),
+              mask_sum=float(o_mask.sum()), oracle_vs_reference=rep,
+              act={k: sample(v) for k, v in captured.items() if k != "pred_full"},
+              pred=sample(pred),
+              unpatchify_pred=sample(model.unpatchify(pred, x)),
+              patchify_x=sample(model.patchify(x)),
+              grads={k: sample(v, 96) for k, v in grads.items()})
+
+    # ---- N-step training curve through the reference's own train_one_epoch ----
+    import engine_pretrain_mae as E
+    from src.utils.lr_sched import get_cosine_schedule_with_warmup
+    hp = TRAIN_HP
+    model = build_reference_model(cfg, params)
+    opt = torch.optim.AdamW(model.parameters(), lr=hp["base_lr"], weight_decay=hp["weight_decay"],
+                            betas=(hp["beta1"], hp["beta2"]))  # optimizers.py:354-360
+    sched = get_cosine_schedule_with_warmup(opt, hp["warmup"], hp["total"], lr_end=hp["min_lr"])
+    nsteps = 4
+    batches = [O.make_volume(cfg, batch, seed + 10 + i) for i in range(nsteps)]
+    noises = [O.make_noise(cfg, batch, seed + 10 + i) for i in range(nsteps)]
+    it = iter(noises)
+    def fake_rand2(*a, **k):
+        return next(it).clone()
+    class Cfg:  # the two attributes train_one_epoch reads (engine_pretrain_mae.py:47,66)
+        class MODEL: NAME = "mae"
+        class TRAIN: GRAD_CLIP = hp["grad_clip"]
+    losses = []
+    class L(logging.Logger):
+        def info(self, msg, *a, **k):
+            if "Loss:" in str(msg):
+                losses.append(float(str(msg).split("Loss:")[1]))
+    lrs = []
+    real_sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None  # engine_pretrain_mae.py:73 (no GPU here)
+    torch.rand = fake_rand2
+    real_step = sched.step
+    def step_spy(*a, **k):
+        lrs.append(opt.param_groups[0]["lr"])
+        return real_step(*a, **k)
+    sched.step = step_spy
+    import warnings
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            stats = E.train_one_epoch(Cfg, model, batches, opt, sched, 0, 1, logger=L("g"), device=torch.device("cpu"),
+                                      use_amp=False, scaler=torch.amp.GradScaler(enabled=False), wandb_run=None)
+    finally:
+        torch.rand = real_rand
+        torch.cuda.synchronize = real_sync
+    # oracle curve
+    st = O.TrainState({k: v.clone() for k, v in params.items()})
+    o_losses, o_lrs = [], []
+    for i in range(nsteps):
+        l, lr, _, _ = O.train_step(cfg, st, batches[i], noises[i], **hp)
+        o_losses.append(l); o_lrs.append(lr)
+    ref_params = dict(model.named_parameters())
+    perrs = {k: rel(st.params[k], ref_params[k].detach()) for k in ref_params}
+    perr = max(perrs.values())
+    print("   worst params:", sorted(perrs.items(), key=lambda kv: -kv[1])[:3])
+    print(f"[{name}] train curve ref {losses} oracle {[round(v, 4) for v in o_losses]} lr {lrs} param-relerr {perr:.2e}")
+    assert np.allclose(losses, o_losses, atol=6e-5), (losses, o_losses)
+    assert np.allclose(lrs, o_lrs, rtol=1e-12), (lrs, o_lrs)
+    # the K-third of attn.qkv.bias has a mathematically ZERO gradient (softmax is invariant to a key bias);
+    # Adam normalises its round-off noise to +-lr, so that slice is compared loosely everywhere.
+    assert perr < 5e-5
+    fx["train"] = dict(hp=hp, steps=nsteps, logged_losses=losses, lrs=lrs, avg_loss=stats["loss"],
+                       params_after={k: sample(v, 64) for k, v in ref_params.items()},
+                       opt_state_keys=sorted(opt.state_dict().keys()),
+                       sched_state_keys=sorted(sched.state_dict().keys()))
+    fx["state_dict_manifest"] = [[k, list(v.shape), str(v.dtype)] for k, v in model.state_dict().items()]
+
+    os.makedirs(HERE, exist_ok=True)
+    with open(os.path.join(HERE, f"{name}_b{batch}_s{seed}.json"), "w") as f:
+        json.dump(fx, f)
+    if full:  # whole tensors for the micro case (small)
+        np.savez_compressed(os.path.join(HERE, f"{name}_b{batch}_s{seed}_full.npz"),
+                            loss=np.float32(float(loss)), pred=pred.numpy(), latent=captured["latent"].numpy(),
+                            **{"grad." + k: v.numpy() for k, v in grads.items()})
+
+
+def lr_schedule_fixture():
+    """Values of the reference's LambdaLR for a canonical schedule (lr_sched.py:18-55)."""
+    from src.utils.lr_sched import get_cosine_schedule_with_warmup
+    p = nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1.5e-4)
+    sched = get_cosine_schedule_with_warmup(opt, 5, 100, lr_end=1.5e-7)
+    vals = []
+    for _ in range(110):
+        vals.append(opt.param_groups[0]["lr"])
+        opt.step(); sched.step()
+    with open(os.path.join(HERE, "lr_schedule.json"), "w") as f:
+        json.dump(dict(base_lr=1.5e-4, min_lr=1.5e-7, warmup=5, total=100, lrs=vals), f)
+
+
+def sincos_fixture():
+    from src.utils.pos_embed import build_sincos_position_embedding
+    out = {}
+    for g, d in ((4, 48), (6, 768), (4, 192)):
+        ref = build_sincos_position_embedding([g, g, g], d, 3).detach()
+        mine = O.build_sincos_position_embedding_3d(g, d)
+        assert torch.equal(ref, mine), (g, d, float((ref - mine).abs().max()))
+        out[f"{g}_{d}"] = sample(ref, 256)
+    with open(os.path.join(HERE, "sincos.json"), "w") as f:
+        json.dump(out, f)
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "reference not mounted: fixtures can only be regenerated in the build container"
+    sys.dont_write_bytecode = True
+    install_standins()
+    sys.path.insert(0, REF)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    sincos_fixture()
+    lr_schedule_fixture()
+    run_case("micro", 2, 0, full=True)
+    run_case("yaml_cut", 2, 1, full=False)
+    run_case("tiny", 2, 0, full=False)
+    run_case("vitb_cut", 2, 0, full=False)
+    print("golden fixtures written to", HERE)
