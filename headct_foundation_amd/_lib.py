@@ -1,0 +1,145 @@
+"""ctypes binding of libheadct_hip.so (include/headct_hip.h).
+
+The product path has NO CPU fallback: if the library is missing or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libheadct_hip.so")
+
+HCT_F32, HCT_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
+
+c_void_p, c_int, c_float, c_size_t, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("A", c_void_p), ("a_dtype", c_int), ("lda", c_int64), ("transA", c_int),
+        ("B", c_void_p), ("b_dtype", c_int), ("ldb", c_int64), ("transB", c_int),
+        ("C", c_void_p), ("c_dtype", c_int), ("ldc", c_int64),
+        ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_int64),
+        ("act", c_int),
+        ("aux", c_void_p), ("aux_dtype", c_int), ("ldaux", c_int64),
+        ("C2", c_void_p), ("c2_dtype", c_int), ("ldc2", c_int64),
+        ("alpha", c_float), ("force_generic", c_int),
+    ]
+
+
+class MaeConfig(C.Structure):
+    _fields_ = [
+        ("input_size", c_int), ("patch_size", c_int), ("in_chans", c_int), ("mask_ratio", c_float),
+        ("pos_embed", c_int),
+        ("encoder_depth", c_int), ("encoder_embed_dim", c_int), ("encoder_mlp_dim", c_int), ("encoder_num_heads", c_int),
+        ("decoder_depth", c_int), ("decoder_embed_dim", c_int), ("decoder_mlp_dim", c_int), ("decoder_num_heads", c_int),
+        ("norm_pix_loss", c_int), ("use_bias", c_int),
+    ]
+
+
+class ParamInfo(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * 96), ("ndim", c_int), ("shape", c_int64 * 5), ("offset", c_int64), ("numel", c_int64),
+        ("requires_grad", c_int), ("is_matrix", c_int), ("bf16_t_offset", c_int64),
+    ]
+
+
+_PROTOS = {
+    # name: (restype, argtypes)
+    "hct_last_error_string": (C.c_char_p, []),
+    "hct_version": (c_int, []),
+    "hct_has_mfma_kernels": (c_int, []),
+    "hct_gemm_workspace_bytes": (c_size_t, [C.POINTER(GemmArgs)]),
+    "hct_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p, c_size_t, c_void_p]),
+    "hct_mask_rank": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hct_patch_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "hct_encoder_assemble_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "hct_encoder_assemble_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hct_assemble_bwd_workspace_bytes": (c_size_t, [c_int]),
+    "hct_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "hct_layernorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "hct_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hct_attention_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "hct_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "hct_debug_force_simple_attention": (None, [c_int]),
+    "hct_decoder_assemble_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "hct_decoder_assemble_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_size_t, c_void_p]),
+    "hct_masked_mse": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hct_unpatchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "hct_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "hct_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hct_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "hct_transpose_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "hct_grad_norms_workspace_bytes": (c_size_t, [c_int64]),
+    "hct_grad_norms": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hct_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_float, c_float,
+                               c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
+    "hct_mae_plan_create": (c_void_p, [C.POINTER(MaeConfig), c_int, c_int]),
+    "hct_mae_plan_destroy": (None, [c_void_p]),
+    "hct_mae_plan_num_params": (c_int, [c_void_p]),
+    "hct_mae_plan_param_info": (c_int, [c_void_p, c_int, C.POINTER(ParamInfo)]),
+    "hct_mae_plan_param_elems": (c_int64, [c_void_p]),
+    "hct_mae_plan_bf16_t_elems": (c_int64, [c_void_p]),
+    "hct_mae_plan_workspace_bytes": (c_size_t, [c_void_p]),
+    "hct_mae_plan_bind": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "hct_mae_refresh_weights": (c_int, [c_void_p, c_int, c_void_p]),
+    "hct_mae_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hct_mae_set_loss_grad": (c_int, [c_void_p, c_void_p]),
+    "hct_mae_num_backward_stages": (c_int, [c_void_p]),
+    "hct_mae_backward_stage_range": (c_int, [c_void_p, c_int, C.POINTER(c_int64), C.POINTER(c_int64)]),
+    "hct_mae_backward_stage": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "hct_mae_plan_activation": (c_void_p, [c_void_p, C.c_char_p, C.POINTER(c_int64), C.POINTER(c_int64), C.POINTER(c_int)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class HctError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Names every build of the library must export (checked by the CPU test-suite)."""
+    return sorted(_PROTOS)
+
+
+def load() -> C.CDLL:
+    """Load libheadct_hip.so; raise loudly if it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HctError(
+            f"{LIB_PATH} not found: build it with `python -m headct_foundation_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the MAE hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().hct_last_error_string()
+        raise HctError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

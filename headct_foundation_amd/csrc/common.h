@@ -1,0 +1,97 @@
+// Shared device/host helpers for libheadct_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/headct_hip.h"
+
+namespace hct {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kWave = 64;
+
+// ---- error plumbing ------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+#define HCT_CHECK_LAUNCH(what)                         \
+  do {                                                 \
+    int _rc = ::hct::check_hip(hipGetLastError(), what); \
+    if (_rc) return _rc;                               \
+  } while (0)
+#define HCT_REQUIRE(cond, ...)       \
+  do {                               \
+    if (!(cond)) {                   \
+      ::hct::set_error(__VA_ARGS__); \
+      return HCT_E_BADARG;           \
+    }                                \
+  } while (0)
+
+inline size_t dtype_size(int dt) { return dt == HCT_BF16 ? 2 : 4; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- scalar load/store by storage type -----------------------------------------------------
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }  // RNE, NaN-preserving cvt
+
+// 4-wide vector access (16 B fp32 / 8 B bf16); pointers must be suitably aligned.
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Vec4<bf16> {
+  static __device__ __forceinline__ f32x4 load(const bf16* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
+  static __device__ __forceinline__ void store(bf16* p, f32x4 v) {
+    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = o;
+  }
+};
+
+// ---- wave / block reductions ---------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact-erf GELU and its derivative (nn.GELU() default; MONAI MLPBlock)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// dispatch a storage dtype code to a template parameter
+#define HCT_DISPATCH_DTYPE(dt, T, ...)                 \
+  do {                                                 \
+    if ((dt) == HCT_BF16) {                            \
+      using T = ::hct::bf16;                           \
+      __VA_ARGS__;                                     \
+    } else {                                           \
+      using T = float;                                 \
+      __VA_ARGS__;                                     \
+    }                                                  \
+  } while (0)
+
+}  // namespace hct

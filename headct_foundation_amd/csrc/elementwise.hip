@@ -1,0 +1,729 @@
+// HBM-bound kernels of the MAE step: masking rank, patch gather, token assembly, LayerNorm fwd/bwd,
+// masked-MSE loss (+ patchify fused), column sums, casts.  All are streaming kernels: one pass over
+// their operands, 16-byte (fp32) / 8-byte (bf16) accesses per lane, wave-per-row where a row reduction
+// is needed (64 lanes x 4 elements = one 1 KiB fp32 request per step).
+#include "common.h"
+
+#include <stdarg.h>
+#include <algorithm>
+
+namespace hct {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return (int)e;
+}
+
+// =============================================================================================
+// masking: rank of each noise value inside its row (stable) -- mae.py:204-216
+// =============================================================================================
+__global__ void mask_rank_kernel(const float* __restrict__ noise, int L, int K, int32_t* __restrict__ ids_restore,
+                                 int32_t* __restrict__ ids_shuffle, float* __restrict__ mask) {
+  extern __shared__ float s_noise[];
+  const int b = blockIdx.x;
+  const float* row = noise + (size_t)b * L;
+  for (int i = threadIdx.x; i < L; i += blockDim.x) s_noise[i] = row[i];
+  __syncthreads();
+  for (int l = threadIdx.x; l < L; l += blockDim.x) {
+    const float v = s_noise[l];
+    int r = 0;
+    for (int j = 0; j < L; ++j) {
+      const float w = s_noise[j];
+      r += (w < v) || (w == v && j < l);
+    }
+    ids_restore[(size_t)b * L + l] = r;
+    ids_shuffle[(size_t)b * L + r] = l;
+    mask[(size_t)b * L + l] = r < K ? 0.0f : 1.0f;
+  }
+}
+
+// =============================================================================================
+// patch gather: kept tokens only, Conv3d weight order (c, ph, pw, pd) -- patch_embedding.py:149
+// =============================================================================================
+template <typename T>
+__global__ void patch_gather_kernel(const float* __restrict__ x, const int32_t* __restrict__ ids_shuffle, int C, int S,
+                                    int P, int L, int K, T* __restrict__ rows) {
+  const int r = blockIdx.x;  // b*K + j
+  const int b = r / K, j = r - b * K;
+  const int g = S / P;
+  const int l = ids_shuffle[(size_t)b * L + j];
+  const int gh = l / (g * g), gw = (l / g) % g, gd = l % g;
+  const int P4 = P >> 2;
+  const int nvec = C * P * P * P4;
+  T* out = rows + (size_t)r * (C * P * P * P);
+  for (int v = threadIdx.x; v < nvec; v += blockDim.x) {
+    int t = v;
+    const int q = t % P4; t /= P4;
+    const int pw = t % P; t /= P;
+    const int ph = t % P; t /= P;
+    const int c = t;
+    const float* src = x + ((((size_t)b * C + c) * S + (gh * P + ph)) * S + (gw * P + pw)) * S + gd * P + q * 4;
+    Vec4<T>::store(out + (size_t)v * 4, Vec4<float>::load(src));
+  }
+}
+
+// =============================================================================================
+// encoder input assembly  -- patch_embedding.py:155-156, mae.py:212,233-234
+// =============================================================================================
+template <typename T>
+__global__ void encoder_assemble_fwd_kernel(const T* __restrict__ tok, const float* __restrict__ cls,
+                                            const float* __restrict__ pos, const int32_t* __restrict__ ids_shuffle,
+                                            int L, int K, int D, float* __restrict__ h0) {
+  const int r = blockIdx.x;  // b*(K+1) + t
+  const int b = r / (K + 1), t = r - b * (K + 1);
+  float* out = h0 + (size_t)r * D;
+  if (t == 0) {
+    for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) Vec4<float>::store(out + d, Vec4<float>::load(cls + d));
+    return;
+  }
+  const int j = t - 1;
+  const int l = ids_shuffle[(size_t)b * L + j];
+  const T* src = tok + ((size_t)b * K + j) * D;
+  for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) {
+    f32x4 v = Vec4<T>::load(src + d);
+    if (pos) v += Vec4<float>::load(pos + (size_t)l * D + d);
+    Vec4<float>::store(out + d, v);
+  }
+}
+
+template <typename T>
+__global__ void encoder_assemble_bwd_tok_kernel(const float* __restrict__ dh0, int K, int D, T* __restrict__ dtok) {
+  const int r = blockIdx.x;  // b*K + j
+  const int b = r / K, j = r - b * K;
+  const float* src = dh0 + ((size_t)b * (K + 1) + 1 + j) * D;
+  T* out = dtok + (size_t)r * D;
+  for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) Vec4<T>::store(out + d, Vec4<float>::load(src + d));
+}
+
+// dpos[l,:] = sum over b with l kept of dh0[b, 1+ids_restore[b,l], :]; fixed b order => deterministic
+__global__ void encoder_assemble_bwd_pos_kernel(const float* __restrict__ dh0, const int32_t* __restrict__ ids_restore,
+                                                int B, int L, int K, int D, float* __restrict__ dpos) {
+  const int l = blockIdx.x;
+  for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) {
+    f32x4 acc = {0, 0, 0, 0};
+    for (int b = 0; b < B; ++b) {
+      const int r = ids_restore[(size_t)b * L + l];
+      if (r < K) acc += Vec4<float>::load(dh0 + ((size_t)b * (K + 1) + 1 + r) * D + d);
+    }
+    Vec4<float>::store(dpos + (size_t)l * D + d, acc);
+  }
+}
+
+// out[d] = sum_b src[b*stride + d]   (row 0 of each volume: cls-token gradients)
+__global__ void strided_rowsum_kernel(const float* __restrict__ src, int B, size_t stride, int D, float* __restrict__ out) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) acc += src[(size_t)b * stride + d];
+  out[d] = acc;
+}
+
+// =============================================================================================
+// LayerNorm forward: one wave per row, two-pass statistics (mean, then centred variance)
+// =============================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int rows, int D, float eps,
+                                                            T* __restrict__ y, float* __restrict__ mean,
+                                                            float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * D;
+  float s = 0.f;
+  for (int d = lane * 4; d < D; d += 256) {
+    f32x4 v = Vec4<float>::load(xr + d);
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int d = lane * 4; d < D; d += 256) {
+    f32x4 v = Vec4<float>::load(xr + d) - mu;
+    q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+  T* yr = y + (size_t)row * D;
+  for (int d = lane * 4; d < D; d += 256) {
+    f32x4 v = (Vec4<float>::load(xr + d) - mu) * rs;
+    v = v * Vec4<float>::load(gamma + d) + Vec4<float>::load(beta + d);
+    Vec4<T>::store(yr + d, v);
+  }
+}
+
+// =============================================================================================
+// LayerNorm backward + residual-gradient add + column partials (dgamma, dbeta, colsum(dx_total)).
+//   dx = rstd * (dy*g - mean_d(dy*g) - xhat * mean_d(dy*g*xhat));   dx_total = dres + dx
+// Each wave walks rows  w, w+W, w+2W ...; lane owns columns {lane*4 + 256*i}; column partials stay in
+// registers (NV compile-time) and are reduced over the block's 4 waves through LDS, then written to
+// partial[block][3][D]; a second kernel folds the partials in fixed order (deterministic).
+// =============================================================================================
+constexpr int kLnBwdBlocks = 512;
+
+template <typename T, typename TS, int NV>
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* dres,
+                                                            int rows, int D, float* dx, TS* __restrict__ shadow,
+                                                            float* __restrict__ partial, int want_colsum) {
+  __shared__ float s_red[4][3][NV * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+  f32x4 g[NV], pg[NV], pb[NV], pc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int d = lane * 4 + 256 * i;
+    g[i] = d < D ? Vec4<float>::load(gamma + d) : f32x4{0, 0, 0, 0};
+    pg[i] = pb[i] = pc[i] = f32x4{0, 0, 0, 0};
+  }
+  for (int row = wid; row < rows; row += nw) {
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 dyv[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int d = lane * 4 + 256 * i;
+      if (d < D) {
+        dyv[i] = Vec4<T>::load(dy + (size_t)row * D + d);
+        xh[i] = (Vec4<float>::load(x + (size_t)row * D + d) - mu) * rs;
+      } else {
+        dyv[i] = xh[i] = f32x4{0, 0, 0, 0};
+      }
+      const f32x4 a = dyv[i] * g[i];
+      const f32x4 bq = a * xh[i];
+      s1 += (a[0] + a[1]) + (a[2] + a[3]);
+      s2 += (bq[0] + bq[1]) + (bq[2] + bq[3]);
+      pg[i] += dyv[i] * xh[i];
+      pb[i] += dyv[i];
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int d = lane * 4 + 256 * i;
+      if (d < D) {
+        f32x4 v = (dyv[i] * g[i] - s1 - xh[i] * s2) * rs;
+        if (dres) v += Vec4<float>::load(dres + (size_t)row * D + d);
+        Vec4<float>::store(dx + (size_t)row * D + d, v);
+        if (shadow) Vec4<TS>::store(shadow + (size_t)row * D + d, v);
+        pc[i] += v;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s_red[wave][0][i * 256 + lane * 4 + e] = pg[i][e];
+      s_red[wave][1][i * 256 + lane * 4 + e] = pb[i][e];
+      s_red[wave][2][i * 256 + lane * 4 + e] = pc[i][e];
+    }
+  }
+  __syncthreads();
+  const int nq = want_colsum ? 3 : 2;
+  for (int idx = threadIdx.x; idx < nq * NV * 256; idx += 256) {
+    const int qn = idx / (NV * 256), c = idx - qn * (NV * 256);
+    if (c < D) {
+      const float v = (s_red[0][qn][c] + s_red[1][qn][c]) + (s_red[2][qn][c] + s_red[3][qn][c]);
+      partial[((size_t)blockIdx.x * 3 + qn) * D + c] = v;
+    }
+  }
+}
+
+// out_q[d] = sum_blocks partial[blk][q][d]
+__global__ void fold_partials_kernel(const float* __restrict__ partial, int nblk, int nq_stride, int D, float* o0,
+                                     float* o1, float* o2) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = blockIdx.y;
+  float* out = q == 0 ? o0 : (q == 1 ? o1 : o2);
+  if (d >= D || out == nullptr) return;
+  float acc = 0.f;
+  for (int b = 0; b < nblk; ++b) acc += partial[((size_t)b * nq_stride + q) * D + d];
+  out[d] = acc;
+}
+
+// =============================================================================================
+// decoder input assembly -- mae.py:257-265
+// =============================================================================================
+template <typename T>
+__global__ void decoder_assemble_fwd_kernel(const T* __restrict__ e, const float* __restrict__ mask_token,
+                                            const float* __restrict__ dec_cls, const float* __restrict__ dec_pos,
+                                            const int32_t* __restrict__ ids_restore, int L, int K, int D,
+                                            float* __restrict__ y) {
+  const int r = blockIdx.x;  // b*(L+1) + t
+  const int b = r / (L + 1), t = r - b * (L + 1);
+  float* out = y + (size_t)r * D;
+  if (t == 0) {
+    const T* src = e + (size_t)b * (K + 1) * D;
+    for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4)
+      Vec4<float>::store(out + d, Vec4<T>::load(src + d) + Vec4<float>::load(dec_cls + d));
+    return;
+  }
+  const int l = t - 1;
+  const int rk = ids_restore[(size_t)b * L + l];
+  const T* src = e + ((size_t)b * (K + 1) + 1 + rk) * D;
+  for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) {
+    f32x4 v = rk < K ? Vec4<T>::load(src + d) : Vec4<float>::load(mask_token + d);
+    Vec4<float>::store(out + d, v + Vec4<float>::load(dec_pos + (size_t)l * D + d));
+  }
+}
+
+template <typename T>
+__global__ void decoder_assemble_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ ids_shuffle, int L,
+                                            int K, int D, T* __restrict__ de) {
+  const int r = blockIdx.x;  // b*(K+1) + t
+  const int b = r / (K + 1), t = r - b * (K + 1);
+  const int srow = t == 0 ? 0 : 1 + ids_shuffle[(size_t)b * L + (t - 1)];
+  const float* src = dy + ((size_t)b * (L + 1) + srow) * D;
+  T* out = de + (size_t)r * D;
+  for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) Vec4<T>::store(out + d, Vec4<float>::load(src + d));
+}
+
+// partial[blk][0][d] = sum over the block's volumes of the masked rows of dy; partial[blk][1][d] = cls rows
+constexpr int kAsmBlocks = 256;
+__global__ void decoder_assemble_bwd_reduce_kernel(const float* __restrict__ dy, const int32_t* __restrict__ ids_shuffle,
+                                                   int B, int L, int K, int D, float* __restrict__ partial) {
+  for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) {
+    f32x4 am = {0, 0, 0, 0}, ac = {0, 0, 0, 0};
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+      const float* base = dy + (size_t)b * (L + 1) * D;
+      ac += Vec4<float>::load(base + d);
+      for (int j = K; j < L; ++j) {
+        const int l = ids_shuffle[(size_t)b * L + j];
+        am += Vec4<float>::load(base + (size_t)(1 + l) * D + d);
+      }
+    }
+    Vec4<float>::store(partial + ((size_t)blockIdx.x * 2 + 0) * D + d, am);
+    Vec4<float>::store(partial + ((size_t)blockIdx.x * 2 + 1) * D + d, ac);
+  }
+}
+
+// =============================================================================================
+// masked MSE fused with patchify (+ optional per-patch target normalisation) -- mae.py:277-301
+// one block per prediction row (b, t); t == 0 is the cls row (dropped, mae.py:273).
+// =============================================================================================
+__device__ __forceinline__ float block_sum_256(float v, float* s_tmp) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (s_tmp[0] + s_tmp[1]) + (s_tmp[2] + s_tmp[3]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) masked_mse_kernel(const T* __restrict__ pred, const float* __restrict__ x,
+                                                         const float* __restrict__ mask, int C, int S, int P, int L,
+                                                         int norm_pix, float inv_masksum, float* __restrict__ row_loss,
+                                                         T* __restrict__ dpred, const float* __restrict__ dscale) {
+  __shared__ float s_tmp[4];
+  const int r = blockIdx.x;
+  const int b = r / (L + 1), t = r - b * (L + 1);
+  const int pd = P * P * P * C;
+  const T* prow = pred + (size_t)r * pd;
+  T* drow = dpred ? dpred + (size_t)r * pd : nullptr;
+  if (t == 0) {
+    if (drow)
+      for (int k = threadIdx.x * 4; k < pd; k += 1024) Vec4<T>::store(drow + k, f32x4{0, 0, 0, 0});
+    return;
+  }
+  const int l = t - 1;
+  const float m = mask[(size_t)b * L + l];
+  if (m == 0.f) {  // kept token: contributes nothing (mask = 0) and has zero gradient
+    if (threadIdx.x == 0 && row_loss) row_loss[(size_t)b * L + l] = 0.f;
+    if (drow)
+      for (int k = threadIdx.x * 4; k < pd; k += 1024) Vec4<T>::store(drow + k, f32x4{0, 0, 0, 0});
+    return;
+  }
+  const int g = S / P;
+  const int gh = l / (g * g), gw = (l / g) % g, gd = l % g;
+  const float* vol = x + (size_t)b * C * S * S * S;
+  auto tgt_at = [&](int k) -> float {  // patchify order (ph, pw, pd, c), c fastest -- mae.py:166-168
+    const int c = k % C;
+    int u = k / C;
+    const int pz = u % P; u /= P;
+    const int pw = u % P; u /= P;
+    const int ph = u;
+    return vol[(((size_t)c * S + (gh * P + ph)) * S + (gw * P + pw)) * S + gd * P + pz];
+  };
+  float mu = 0.f, rsd = 1.f;
+  if (norm_pix) {
+    float s = 0.f;
+    for (int k = threadIdx.x; k < pd; k += 256) s += tgt_at(k);
+    mu = block_sum_256(s, s_tmp) / (float)pd;
+    float q = 0.f;
+    for (int k = threadIdx.x; k < pd; k += 256) {
+      const float dlt = tgt_at(k) - mu;
+      q += dlt * dlt;
+    }
+    const float var = block_sum_256(q, s_tmp) / (float)(pd - 1);  // unbiased, mae.py:292
+    rsd = 1.0f / sqrtf(var + 1.0e-6f);
+  }
+  const float gscale = 2.0f * inv_masksum / (float)pd * (dscale ? *dscale : 1.0f);
+  float sse = 0.f;
+  if (C == 1) {
+    for (int k = threadIdx.x * 4; k < pd; k += 1024) {
+      int u = k;
+      const int pz = u % P; u /= P;
+      const int pw = u % P; u /= P;
+      const int ph = u;
+      f32x4 tv = Vec4<float>::load(vol + ((size_t)(gh * P + ph) * S + (gw * P + pw)) * S + gd * P + pz);
+      tv = (tv - mu) * rsd;
+      const f32x4 df = Vec4<T>::load(prow + k) - tv;
+      sse += (df[0] * df[0] + df[1] * df[1]) + (df[2] * df[2] + df[3] * df[3]);
+      if (drow) Vec4<T>::store(drow + k, df * gscale);
+    }
+  } else {
+    for (int k = threadIdx.x; k < pd; k += 256) {
+      const float df = to_f32(prow[k]) - (tgt_at(k) - mu) * rsd;
+      sse += df * df;
+      if (drow) drow[k] = from_f32<T>(df * gscale);
+    }
+  }
+  sse = block_sum_256(sse, s_tmp);
+  if (threadIdx.x == 0 && row_loss) row_loss[(size_t)b * L + l] = sse / (float)pd;
+}
+
+__global__ void __launch_bounds__(256) loss_fold_kernel(const float* __restrict__ row_loss, int n, float inv_masksum,
+                                                        float* __restrict__ loss) {
+  __shared__ float s_tmp[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += row_loss[i];
+  s = block_sum_256(s, s_tmp);
+  if (threadIdx.x == 0) *loss = s * inv_masksum;
+}
+
+template <typename T>
+__global__ void unpatchify_kernel(const T* __restrict__ pred, int has_cls, int C, int S, int P, float* __restrict__ vol) {
+  // one block per (b, l); writes the patch's voxels -- mae.py:188-190
+  const int g = S / P, L = g * g * g;
+  const int r = blockIdx.x;
+  const int b = r / L, l = r - b * L;
+  const int gh = l / (g * g), gw = (l / g) % g, gd = l % g;
+  const int pd = P * P * P * C;
+  const T* prow = pred + ((size_t)b * (L + has_cls) + has_cls + l) * pd;
+  for (int k = threadIdx.x; k < pd; k += blockDim.x) {
+    const int c = k % C;
+    int u = k / C;
+    const int pz = u % P; u /= P;
+    const int pw = u % P; u /= P;
+    const int ph = u;
+    vol[((((size_t)b * C + c) * S + (gh * P + ph)) * S + (gw * P + pw)) * S + gd * P + pz] = to_f32(prow[k]);
+  }
+}
+
+// =============================================================================================
+// column sums (bias gradients): grid (col blocks of 256, row chunks) -> partial -> fold
+// =============================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const T* __restrict__ x, int rows, int cols, int64_t ld,
+                                                             int rows_per_chunk, float* __restrict__ partial) {
+  __shared__ float s_red[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 256 + lane * 4;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(rows, r0 + rows_per_chunk);
+  f32x4 acc = {0, 0, 0, 0};
+  if (c0 < cols)
+    for (int r = r0 + wave; r < r1; r += 4) acc += Vec4<T>::load(x + (size_t)r * ld + c0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s_red[wave][lane * 4 + e] = acc[e];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < cols)
+    partial[(size_t)blockIdx.y * cols + c] =
+        (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
+// =============================================================================================
+// casts
+// =============================================================================================
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      Vec4<TO>::store(dst + i, Vec4<TI>::load(src + i));
+    } else {
+      for (int64_t k = i; k < n; ++k) dst[k] = from_f32<TO>(to_f32(src[k]));
+    }
+  }
+}
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) transpose_cast_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int rows,
+                                                             int cols) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? to_f32(src[(size_t)r * cols + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;  // dst[c][r]
+    if (c < cols && r < rows) dst[(size_t)c * rows + r] = from_f32<TO>(tile[tx][i]);
+  }
+}
+
+}  // namespace hct
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+using namespace hct;
+
+template <typename T, typename TS>
+static int launch_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                         const float* dres, int rows, int D, float* dx, void* shadow, float* partial, int want_colsum,
+                         int nblk, hipStream_t s) {
+#define HCT_LN_CASE(NV)                                                                                               \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<T, TS, NV>), dim3(nblk), dim3(256), 0, s, (const T*)dy, x, mean, rstd, gamma, \
+                     dres, rows, D, dx, (TS*)shadow, partial, want_colsum)
+  const int nv = (D + 255) / 256;
+  switch (nv) {
+    case 1: HCT_LN_CASE(1); break;
+    case 2: HCT_LN_CASE(2); break;
+    case 3: HCT_LN_CASE(3); break;
+    case 4: HCT_LN_CASE(4); break;
+    default: set_error("hct_layernorm_bwd: D=%d > 1024 unsupported", D); return HCT_E_UNSUPPORTED;
+  }
+#undef HCT_LN_CASE
+  return 0;
+}
+
+extern "C" {
+
+const char* hct_last_error_string(void) { return g_err; }
+int hct_version(void) { return 100; }
+int hct_has_mfma_kernels(void) { return 1; }
+
+int hct_mask_rank(const float* noise, int B, int L, int K, int32_t* ids_restore, int32_t* ids_shuffle, float* mask,
+                  void* stream) {
+  HCT_REQUIRE(B > 0 && L > 0 && K >= 0 && K <= L && L <= 12288, "hct_mask_rank: bad shape B=%d L=%d K=%d", B, L, K);
+  hipLaunchKernelGGL(mask_rank_kernel, dim3(B), dim3(256), L * sizeof(float), (hipStream_t)stream, noise, L, K,
+                     ids_restore, ids_shuffle, mask);
+  HCT_CHECK_LAUNCH("hct_mask_rank");
+  return 0;
+}
+
+int hct_patch_gather(const float* x, const int32_t* ids_shuffle, int B, int C, int S, int P, int L, int K, void* rows,
+                     int rows_dtype, void* stream) {
+  HCT_REQUIRE(P % 4 == 0 && S % P == 0 && (S / P) * (S / P) * (S / P) == L, "hct_patch_gather: bad geometry S=%d P=%d L=%d", S, P, L);
+  if (B * K == 0) return 0;
+  HCT_DISPATCH_DTYPE(rows_dtype, T,
+                     hipLaunchKernelGGL(patch_gather_kernel<T>, dim3(B * K), dim3(256), 0, (hipStream_t)stream, x,
+                                        ids_shuffle, C, S, P, L, K, (T*)rows));
+  HCT_CHECK_LAUNCH("hct_patch_gather");
+  return 0;
+}
+
+int hct_encoder_assemble_fwd(const void* tok, int tok_dtype, const float* cls, const float* pos,
+                             const int32_t* ids_shuffle, int B, int L, int K, int D, float* h0, void* stream) {
+  HCT_REQUIRE(D % 4 == 0, "hct_encoder_assemble_fwd: D %% 4 != 0 (%d)", D);
+  const int threads = D / 4 >= 256 ? 256 : (D / 4 > 64 ? 128 : 64);
+  HCT_DISPATCH_DTYPE(tok_dtype, T,
+                     hipLaunchKernelGGL(encoder_assemble_fwd_kernel<T>, dim3(B * (K + 1)), dim3(threads), 0,
+                                        (hipStream_t)stream, (const T*)tok, cls, pos, ids_shuffle, L, K, D, h0));
+  HCT_CHECK_LAUNCH("hct_encoder_assemble_fwd");
+  return 0;
+}
+
+size_t hct_assemble_bwd_workspace_bytes(int D) { return (size_t)kAsmBlocks * 2 * D * sizeof(float); }
+
+int hct_encoder_assemble_bwd(const float* dh0, const int32_t* ids_restore, int B, int L, int K, int D, void* dtok,
+                             int dtok_dtype, float* dcls, float* dpos, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  (void)workspace; (void)workspace_bytes;
+  HCT_REQUIRE(D % 4 == 0, "hct_encoder_assemble_bwd: D %% 4 != 0 (%d)", D);
+  const int threads = D / 4 >= 256 ? 256 : (D / 4 > 64 ? 128 : 64);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtok && B * K > 0)
+    HCT_DISPATCH_DTYPE(dtok_dtype, T,
+                       hipLaunchKernelGGL(encoder_assemble_bwd_tok_kernel<T>, dim3(B * K), dim3(threads), 0, s, dh0, K, D,
+                                          (T*)dtok));
+  if (dcls) hipLaunchKernelGGL(strided_rowsum_kernel, dim3((D + 255) / 256), dim3(256), 0, s, dh0, B, (size_t)(K + 1) * D, D, dcls);
+  if (dpos) hipLaunchKernelGGL(encoder_assemble_bwd_pos_kernel, dim3(L), dim3(threads), 0, s, dh0, ids_restore, B, L, K, D, dpos);
+  HCT_CHECK_LAUNCH("hct_encoder_assemble_bwd");
+  return 0;
+}
+
+int hct_layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int D, float eps, void* y,
+                      int y_dtype, float* mean, float* rstd, void* stream) {
+  HCT_REQUIRE(D % 4 == 0 && rows >= 0, "hct_layernorm_fwd: bad shape rows=%d D=%d", rows, D);
+  if (rows == 0) return 0;
+  HCT_DISPATCH_DTYPE(y_dtype, T,
+                     hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                                        x, gamma, beta, rows, D, eps, (T*)y, mean, rstd));
+  HCT_CHECK_LAUNCH("hct_layernorm_fwd");
+  return 0;
+}
+
+size_t hct_layernorm_bwd_workspace_bytes(int rows, int D) {
+  (void)rows;
+  return (size_t)kLnBwdBlocks * 3 * D * sizeof(float);
+}
+
+int hct_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
+                      const float* gamma, const float* dres, int rows, int D, float* dx, void* dx_shadow,
+                      int shadow_dtype, float* dgamma, float* dbeta, float* dcolsum, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  HCT_REQUIRE(D % 4 == 0 && rows > 0, "hct_layernorm_bwd: bad shape rows=%d D=%d", rows, D);
+  if (workspace_bytes < hct_layernorm_bwd_workspace_bytes(rows, D)) {
+    set_error("hct_layernorm_bwd: workspace too small");
+    return HCT_E_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = min(kLnBwdBlocks, (rows + 3) / 4);
+  float* partial = (float*)workspace;
+  int rc = 0;
+  if (dy_dtype == HCT_BF16) {
+    if (dx_shadow && shadow_dtype == HCT_F32) rc = launch_ln_bwd<bf16, float>(dy, x, mean, rstd, gamma, dres, rows, D, dx, dx_shadow, partial, dcolsum != nullptr, nblk, s);
+    else rc = launch_ln_bwd<bf16, bf16>(dy, x, mean, rstd, gamma, dres, rows, D, dx, dx_shadow, partial, dcolsum != nullptr, nblk, s);
+  } else {
+    if (dx_shadow && shadow_dtype == HCT_BF16) rc = launch_ln_bwd<float, bf16>(dy, x, mean, rstd, gamma, dres, rows, D, dx, dx_shadow, partial, dcolsum != nullptr, nblk, s);
+    else rc = launch_ln_bwd<float, float>(dy, x, mean, rstd, gamma, dres, rows, D, dx, dx_shadow, partial, dcolsum != nullptr, nblk, s);
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((D + 255) / 256, dcolsum ? 3 : 2), dim3(256), 0, s, partial, nblk, 3, D,
+                     dgamma, dbeta, dcolsum);
+  HCT_CHECK_LAUNCH("hct_layernorm_bwd");
+  return 0;
+}
+
+int hct_decoder_assemble_fwd(const void* e, int e_dtype, const float* mask_token, const float* dec_cls,
+                             const float* dec_pos, const int32_t* ids_restore, int B, int L, int K, int D, float* y,
+                             void* stream) {
+  HCT_REQUIRE(D % 4 == 0, "hct_decoder_assemble_fwd: D %% 4 != 0 (%d)", D);
+  const int threads = D / 4 >= 256 ? 256 : (D / 4 > 64 ? 128 : 64);
+  HCT_DISPATCH_DTYPE(e_dtype, T,
+                     hipLaunchKernelGGL(decoder_assemble_fwd_kernel<T>, dim3(B * (L + 1)), dim3(threads), 0,
+                                        (hipStream_t)stream, (const T*)e, mask_token, dec_cls, dec_pos, ids_restore, L, K,
+                                        D, y));
+  HCT_CHECK_LAUNCH("hct_decoder_assemble_fwd");
+  return 0;
+}
+
+int hct_decoder_assemble_bwd(const float* dy, const int32_t* ids_restore, const int32_t* ids_shuffle, int B, int L,
+                             int K, int D, void* de, int de_dtype, float* dmask_token, float* ddec_cls,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  (void)ids_restore;
+  HCT_REQUIRE(D % 4 == 0, "hct_decoder_assemble_bwd: D %% 4 != 0 (%d)", D);
+  if (workspace_bytes < hct_assemble_bwd_workspace_bytes(D)) {
+    set_error("hct_decoder_assemble_bwd: workspace too small");
+    return HCT_E_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int threads = D / 4 >= 256 ? 256 : (D / 4 > 64 ? 128 : 64);
+  HCT_DISPATCH_DTYPE(de_dtype, T,
+                     hipLaunchKernelGGL(decoder_assemble_bwd_kernel<T>, dim3(B * (K + 1)), dim3(threads), 0, s, dy,
+                                        ids_shuffle, L, K, D, (T*)de));
+  const int nblk = min(B, kAsmBlocks);
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(decoder_assemble_bwd_reduce_kernel, dim3(nblk), dim3(threads), 0, s, dy, ids_shuffle, B, L, K, D, partial);
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((D + 255) / 256, 2), dim3(256), 0, s, partial, nblk, 2, D, dmask_token,
+                     ddec_cls, (float*)nullptr);
+  HCT_CHECK_LAUNCH("hct_decoder_assemble_bwd");
+  return 0;
+}
+
+int hct_masked_mse(const void* pred, int pred_dtype, const float* x, const float* mask, int B, int C, int S, int P,
+                   int norm_pix, float mask_sum, float* row_loss, float* loss, void* dpred, const float* dpred_scale,
+                   void* stream) {
+  HCT_REQUIRE(P % 4 == 0 && S % P == 0 && mask_sum > 0.f, "hct_masked_mse: bad geometry S=%d P=%d mask_sum=%f", S, P, mask_sum);
+  const int g = S / P, L = g * g * g;
+  const int pd = P * P * P * C;
+  HCT_REQUIRE(pd % 4 == 0, "hct_masked_mse: patch dim %% 4 != 0");
+  hipStream_t s = (hipStream_t)stream;
+  const float inv = 1.0f / mask_sum;
+  HCT_DISPATCH_DTYPE(pred_dtype, T,
+                     hipLaunchKernelGGL(masked_mse_kernel<T>, dim3(B * (L + 1)), dim3(256), 0, s, (const T*)pred, x, mask,
+                                        C, S, P, L, norm_pix, inv, loss ? row_loss : nullptr, (T*)dpred, dpred_scale));
+  if (loss) hipLaunchKernelGGL(loss_fold_kernel, dim3(1), dim3(256), 0, s, row_loss, B * L, inv, loss);
+  HCT_CHECK_LAUNCH("hct_masked_mse");
+  return 0;
+}
+
+int hct_unpatchify(const void* pred, int pred_dtype, int has_cls_row, int B, int C, int S, int P, float* vol,
+                   void* stream) {
+  HCT_REQUIRE(S % P == 0, "hct_unpatchify: bad geometry");
+  const int g = S / P, L = g * g * g;
+  HCT_DISPATCH_DTYPE(pred_dtype, T,
+                     hipLaunchKernelGGL(unpatchify_kernel<T>, dim3(B * L), dim3(256), 0, (hipStream_t)stream,
+                                        (const T*)pred, has_cls_row ? 1 : 0, C, S, P, vol));
+  HCT_CHECK_LAUNCH("hct_unpatchify");
+  return 0;
+}
+
+static int colsum_chunks(int rows, int cols) {
+  const int colblk = (cols + 255) / 256;
+  int chunks = (1024 + colblk - 1) / colblk;
+  if (chunks > (rows + 15) / 16) chunks = (rows + 15) / 16;
+  return chunks < 1 ? 1 : chunks;
+}
+size_t hct_colsum_workspace_bytes(int rows, int cols) { return (size_t)colsum_chunks(rows, cols) * cols * sizeof(float); }
+
+int hct_colsum(const void* x, int dtype, int rows, int cols, int64_t ld, float* out, void* workspace,
+               size_t workspace_bytes, void* stream) {
+  HCT_REQUIRE(cols % 4 == 0 && ld % 4 == 0 && rows > 0, "hct_colsum: cols/ld must be multiples of 4");
+  if (workspace_bytes < hct_colsum_workspace_bytes(rows, cols)) {
+    set_error("hct_colsum: workspace too small");
+    return HCT_E_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = colsum_chunks(rows, cols);
+  const int rpc = (rows + chunks - 1) / chunks;
+  float* partial = (float*)workspace;
+  HCT_DISPATCH_DTYPE(dtype, T,
+                     hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3((cols + 255) / 256, chunks), dim3(256), 0, s,
+                                        (const T*)x, rows, cols, ld, rpc, partial));
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((cols + 255) / 256, 1), dim3(256), 0, s, partial, chunks, 1, cols, out,
+                     (float*)nullptr, (float*)nullptr);
+  HCT_CHECK_LAUNCH("hct_colsum");
+  return 0;
+}
+
+int hct_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
+  if (n <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = (int)std::min<int64_t>(2048, (n + 1023) / 1024);
+  if (src_dtype == HCT_F32 && dst_dtype == HCT_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(blocks), dim3(256), 0, s, (const float*)src, (bf16*)dst, n);
+  else if (src_dtype == HCT_BF16 && dst_dtype == HCT_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(blocks), dim3(256), 0, s, (const bf16*)src, (float*)dst, n);
+  else if (src_dtype == HCT_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, s, (const float*)src, (float*)dst, n);
+  else
+    hipLaunchKernelGGL((cast_kernel<bf16, bf16>), dim3(blocks), dim3(256), 0, s, (const bf16*)src, (bf16*)dst, n);
+  HCT_CHECK_LAUNCH("hct_cast");
+  return 0;
+}
+
+int hct_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int rows, int cols, void* stream) {
+  if (rows <= 0 || cols <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  if (src_dtype == HCT_F32 && dst_dtype == HCT_BF16)
+    hipLaunchKernelGGL((transpose_cast_kernel<float, bf16>), grid, dim3(256), 0, s, (const float*)src, (bf16*)dst, rows, cols);
+  else if (src_dtype == HCT_F32 && dst_dtype == HCT_F32)
+    hipLaunchKernelGGL((transpose_cast_kernel<float, float>), grid, dim3(256), 0, s, (const float*)src, (float*)dst, rows, cols);
+  else if (src_dtype == HCT_BF16 && dst_dtype == HCT_BF16)
+    hipLaunchKernelGGL((transpose_cast_kernel<bf16, bf16>), grid, dim3(256), 0, s, (const bf16*)src, (bf16*)dst, rows, cols);
+  else
+    hipLaunchKernelGGL((transpose_cast_kernel<bf16, float>), grid, dim3(256), 0, s, (const bf16*)src, (float*)dst, rows, cols);
+  HCT_CHECK_LAUNCH("hct_transpose_cast");
+  return 0;
+}
+
+}  // extern "C"

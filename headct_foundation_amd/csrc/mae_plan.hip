@@ -1,0 +1,527 @@
+// Whole-model driver: parameter layout, activation workspace layout, forward and staged backward of
+// MaskedAutoencoderViT (src/models/mae.py:220-317; AttentionBlock attentionblock.py:96-99) on one GPU.
+// Host-only logic: it owns no device memory and launches the kernels of this library on the caller's stream.
+//
+// Flat parameter layout (element offsets, every tensor starts on a 1024-element unit): tensors are laid out in
+// FORWARD-USE order  [patch-embed w,b | pos | cls | enc block 0 .. | norm | decoder_embed | mask_token | dec_cls |
+// dec_pos | dec block 0 .. | decoder_norm | decoder_pred]  so that each backward stage completes one contiguous
+// range and the ranges finish from the end of the buffer towards its start (gradient-bucket order for the
+// data-parallel all-reduce).  Names/shapes are the reference's; the Python side builds
+// nn.Parameter views by name, so state_dict order/keys are the reference's regardless of this layout.
+#include "common.h"
+
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace hct;
+
+namespace {
+
+constexpr int64_t kUnitElems = 1024;
+
+struct BlockP {  // parameter indices
+  int ln1_w, ln1_b, qkv_w, qkv_b, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b;
+};
+struct BlockA {  // byte offsets into the workspace
+  size_t x1, mean1, rstd1, qkv, o, lse, h_mid, x2, mean2, rstd2, u, g;
+};
+struct Act { size_t off; int64_t rows, cols; int dtype; };
+
+}  // namespace
+
+struct hct_mae_plan {
+  hct_mae_config cfg;
+  int B, dt;           // batch, compute dtype
+  int g, L, K, pd, Ne, Nd, Me, Md;
+  int D, Dd, Mlp, Mlpd, H, Hd;
+  std::vector<hct_param_info> params;
+  std::map<std::string, int> pindex;
+  int64_t param_elems = 0, bf16t_elems = 0;
+  // parameter indices
+  int p_pe_w, p_pe_b, p_pos, p_cls, p_norm_w, p_norm_b, p_de_w, p_de_b, p_mask, p_dcls, p_dpos, p_dnorm_w, p_dnorm_b,
+      p_pred_w, p_pred_b;
+  std::vector<BlockP> enc, dec;
+  // stage -> parameter range
+  std::vector<std::pair<int64_t, int64_t>> stage_range;
+  // workspace
+  size_t ws_bytes = 0;
+  size_t a_ids_restore, a_ids_shuffle, a_mask, a_row_loss, a_patches, a_tok, a_latent, a_lat_mean, a_lat_rstd, a_e,
+      a_ynorm, a_yn_mean, a_yn_rstd, a_pred, a_dpred;
+  std::vector<size_t> h_enc, h_dec;  // fp32 residual-stream chain
+  std::vector<BlockA> aenc, adec;
+  size_t s_dh, s_dh_shadow, s_dbig, s_dx, s_do, s_dqkv, s_small, s_small_bytes, s_gemm, s_gemm_bytes;
+  std::map<std::string, Act> acts;
+  // bound buffers
+  float* params_f32 = nullptr;
+  float* grads = nullptr;
+  bf16* params_bf16 = nullptr;
+  bf16* params_bf16_t = nullptr;
+  unsigned char* ws = nullptr;
+  bool fwd_done = false;
+  const float* dloss = nullptr;
+
+  size_t esz() const { return dtype_size(dt); }
+  template <typename T> T* W(size_t off) const { return reinterpret_cast<T*>(ws + off); }
+  const float* pf(int i) const { return i < 0 ? nullptr : params_f32 + params[i].offset; }
+  float* gf(int i) const { return i < 0 ? nullptr : grads + params[i].offset; }
+  // weight operand in the compute dtype
+  const void* wop(int i) const { return dt == HCT_BF16 ? (const void*)(params_bf16 + params[i].offset) : (const void*)(params_f32 + params[i].offset); }
+  const void* wop_t(int i) const { return (const void*)(params_bf16_t + params[i].bf16_t_offset); }
+};
+
+namespace {
+
+int add_param(hct_mae_plan* p, const std::string& name, std::vector<int64_t> shape, bool rg, bool matrix, bool needs_t) {
+  hct_param_info pi;
+  memset(&pi, 0, sizeof(pi));
+  snprintf(pi.name, sizeof(pi.name), "%s", name.c_str());
+  pi.ndim = (int)shape.size();
+  int64_t n = 1;
+  for (size_t i = 0; i < shape.size(); ++i) { pi.shape[i] = shape[i]; n *= shape[i]; }
+  pi.numel = n;
+  pi.offset = p->param_elems;
+  pi.requires_grad = rg ? 1 : 0;
+  pi.is_matrix = matrix ? 1 : 0;
+  pi.bf16_t_offset = -1;
+  if (needs_t) {
+    pi.bf16_t_offset = p->bf16t_elems;
+    p->bf16t_elems += (n + 63) / 64 * 64;
+  }
+  p->param_elems += (n + kUnitElems - 1) / kUnitElems * kUnitElems;
+  p->params.push_back(pi);
+  p->pindex[name] = (int)p->params.size() - 1;
+  return (int)p->params.size() - 1;
+}
+
+BlockP add_block(hct_mae_plan* p, const std::string& pre, int d, int m, bool use_bias) {
+  BlockP b;
+  b.ln1_w = add_param(p, pre + ".att_norm.weight", {d}, true, false, false);
+  b.ln1_b = add_param(p, pre + ".att_norm.bias", {d}, true, false, false);
+  b.qkv_w = add_param(p, pre + ".attn.qkv.weight", {3 * d, d}, true, true, true);
+  b.qkv_b = use_bias ? add_param(p, pre + ".attn.qkv.bias", {3 * d}, true, false, false) : -1;
+  b.proj_w = add_param(p, pre + ".attn.proj.weight", {d, d}, true, true, true);
+  b.proj_b = add_param(p, pre + ".attn.proj.bias", {d}, true, false, false);
+  b.ln2_w = add_param(p, pre + ".ffn_norm.weight", {d}, true, false, false);
+  b.ln2_b = add_param(p, pre + ".ffn_norm.bias", {d}, true, false, false);
+  b.fc1_w = add_param(p, pre + ".mlp.linear1.weight", {m, d}, true, true, true);
+  b.fc1_b = add_param(p, pre + ".mlp.linear1.bias", {m}, true, false, false);
+  b.fc2_w = add_param(p, pre + ".mlp.linear2.weight", {d, m}, true, true, true);
+  b.fc2_b = add_param(p, pre + ".mlp.linear2.bias", {d}, true, false, false);
+  return b;
+}
+
+struct WsAlloc {
+  size_t cur = 0;
+  size_t take(size_t bytes) {
+    size_t o = cur;
+    cur += align_up(bytes ? bytes : 16, 256);
+    return o;
+  }
+};
+
+BlockA alloc_block(WsAlloc& w, size_t M, size_t d, size_t m, size_t heads_tokens, size_t es) {
+  BlockA a;
+  a.x1 = w.take(M * d * es);
+  a.mean1 = w.take(M * 4);
+  a.rstd1 = w.take(M * 4);
+  a.qkv = w.take(M * 3 * d * es);
+  a.o = w.take(M * d * es);
+  a.lse = w.take(heads_tokens * 4);
+  a.h_mid = w.take(M * d * 4);
+  a.x2 = w.take(M * d * es);
+  a.mean2 = w.take(M * 4);
+  a.rstd2 = w.take(M * 4);
+  a.u = w.take(M * m * es);
+  a.g = w.take(M * m * es);
+  return a;
+}
+
+// ---- GEMM helpers -----------------------------------------------------------------------------------------------
+hct_gemm_args base_args() {
+  hct_gemm_args a;
+  memset(&a, 0, sizeof(a));
+  a.alpha = 1.0f;
+  return a;
+}
+
+// Y[M,N] = act(X[M,K] . W[N,K]^T + b) (+ residual)
+int linear_fwd(hct_mae_plan* p, const void* X, int M, int K, int w, int b, int N, void* Y, int y_dtype, int act, void* aux,
+               const float* residual, hipStream_t s) {
+  hct_gemm_args a = base_args();
+  a.M = M; a.N = N; a.K = K;
+  a.A = X; a.a_dtype = p->dt; a.lda = K; a.transA = 0;
+  a.B = p->wop(w); a.b_dtype = p->dt; a.ldb = K; a.transB = 1;
+  a.C = Y; a.c_dtype = y_dtype; a.ldc = N;
+  a.bias = p->pf(b);
+  a.residual = residual; a.ldr = N;
+  a.act = act; a.aux = aux; a.aux_dtype = p->dt; a.ldaux = N;
+  return hct_gemm(&a, nullptr, 0, s);
+}
+
+// dX[M,K] = dY[M,N] . W[N,K]   (optionally * gelu'(aux))
+int linear_dgrad(hct_mae_plan* p, const void* dY, int M, int N, int w, int K, void* dX, int act, void* aux, hipStream_t s) {
+  hct_gemm_args a = base_args();
+  a.M = M; a.N = K; a.K = N;
+  a.A = dY; a.a_dtype = p->dt; a.lda = N; a.transA = 0;
+  if (p->dt == HCT_BF16) { a.B = p->wop_t(w); a.b_dtype = HCT_BF16; a.ldb = N; a.transB = 1; }  // W^T stored [K,N]
+  else { a.B = p->wop(w); a.b_dtype = HCT_F32; a.ldb = K; a.transB = 0; }
+  a.C = dX; a.c_dtype = p->dt; a.ldc = K;
+  a.act = act; a.aux = aux; a.aux_dtype = p->dt; a.ldaux = K;
+  return hct_gemm(&a, nullptr, 0, s);
+}
+
+// dW[N,K] = dY[M,N]^T . X[M,K]  (fp32 gradient); optional bias gradient = colsum(dY)
+int linear_wgrad(hct_mae_plan* p, const void* dY, const void* X, int M, int N, int K, int w, int b, hipStream_t s) {
+  hct_gemm_args a = base_args();
+  a.M = N; a.N = K; a.K = M;
+  a.A = dY; a.a_dtype = p->dt; a.lda = N; a.transA = 1;
+  a.B = X; a.b_dtype = p->dt; a.ldb = K; a.transB = 0;
+  a.C = p->gf(w); a.c_dtype = HCT_F32; a.ldc = K;
+  int rc = hct_gemm(&a, p->ws + p->s_gemm, p->s_gemm_bytes, s);
+  if (rc) return rc;
+  if (b >= 0) rc = hct_colsum(dY, p->dt, M, N, N, p->gf(b), p->ws + p->s_small, p->s_small_bytes, s);
+  return rc;
+}
+
+size_t wgrad_ws(int dt, int M, int N, int K) {
+  hct_gemm_args a = base_args();
+  a.M = N; a.N = K; a.K = M;
+  a.a_dtype = dt; a.b_dtype = dt; a.lda = N; a.ldb = K; a.transA = 1; a.transB = 0; a.ldc = K; a.c_dtype = HCT_F32;
+  a.A = (const void*)256; a.B = (const void*)256; a.C = (void*)256;  // alignment probes only
+  return hct_gemm_workspace_bytes(&a);
+}
+
+#define RC(x)            \
+  do {                   \
+    int _rc = (x);       \
+    if (_rc) return _rc; \
+  } while (0)
+
+int block_forward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const float* h_in, float* h_out, int B, int N, int d,
+                  int m, int heads, hipStream_t s) {
+  const int M = B * N;
+  unsigned char* ws = p->ws;
+  RC(hct_layernorm_fwd(h_in, p->pf(bp.ln1_w), p->pf(bp.ln1_b), M, d, 1e-5f, ws + ba.x1, p->dt, (float*)(ws + ba.mean1), (float*)(ws + ba.rstd1), s));
+  RC(linear_fwd(p, ws + ba.x1, M, d, bp.qkv_w, bp.qkv_b, 3 * d, ws + ba.qkv, p->dt, HCT_ACT_NONE, nullptr, nullptr, s));
+  RC(hct_attention_fwd(ws + ba.qkv, B, N, heads, d / heads, p->dt, ws + ba.o, (float*)(ws + ba.lse), s));
+  RC(linear_fwd(p, ws + ba.o, M, d, bp.proj_w, bp.proj_b, d, ws + ba.h_mid, HCT_F32, HCT_ACT_NONE, nullptr, h_in, s));
+  RC(hct_layernorm_fwd((const float*)(ws + ba.h_mid), p->pf(bp.ln2_w), p->pf(bp.ln2_b), M, d, 1e-5f, ws + ba.x2, p->dt, (float*)(ws + ba.mean2), (float*)(ws + ba.rstd2), s));
+  RC(linear_fwd(p, ws + ba.x2, M, d, bp.fc1_w, bp.fc1_b, m, ws + ba.g, p->dt, HCT_ACT_GELU, ws + ba.u, nullptr, s));
+  RC(linear_fwd(p, ws + ba.g, M, m, bp.fc2_w, bp.fc2_b, d, h_out, HCT_F32, HCT_ACT_NONE, nullptr, (const float*)(ws + ba.h_mid), s));
+  return 0;
+}
+
+// in: dh (fp32 [M,d]) + shadow (compute dtype) = gradient wrt the block output.  out: same buffers hold the gradient
+// wrt the block input.  prev_fc2_b: bias index that receives colsum(d h_in) (the previous block's linear2 bias), or -1.
+int block_backward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const float* h_in, int B, int N, int d, int m,
+                   int heads, int prev_fc2_b, hipStream_t s) {
+  const int M = B * N;
+  unsigned char* ws = p->ws;
+  float* dh = (float*)(ws + p->s_dh);
+  void* dhs = ws + p->s_dh_shadow;
+  void* dbig = ws + p->s_dbig;
+  void* dx = ws + p->s_dx;
+  void* d_o = ws + p->s_do;
+  void* dqkv = ws + p->s_dqkv;
+  void* small = ws + p->s_small;
+  // MLP branch
+  RC(linear_wgrad(p, dhs, ws + ba.g, M, d, m, bp.fc2_w, -1, s));
+  RC(linear_dgrad(p, dhs, M, d, bp.fc2_w, m, dbig, HCT_ACT_DGELU, ws + ba.u, s));
+  RC(linear_wgrad(p, dbig, ws + ba.x2, M, m, d, bp.fc1_w, bp.fc1_b, s));
+  RC(linear_dgrad(p, dbig, M, m, bp.fc1_w, d, dx, HCT_ACT_NONE, nullptr, s));
+  RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + ba.h_mid), (const float*)(ws + ba.mean2), (const float*)(ws + ba.rstd2),
+                       p->pf(bp.ln2_w), dh, M, d, dh, dhs, p->dt, p->gf(bp.ln2_w), p->gf(bp.ln2_b), p->gf(bp.proj_b), small,
+                       p->s_small_bytes, s));
+  // attention branch
+  RC(linear_wgrad(p, dhs, ws + ba.o, M, d, d, bp.proj_w, -1, s));
+  RC(linear_dgrad(p, dhs, M, d, bp.proj_w, d, d_o, HCT_ACT_NONE, nullptr, s));
+  RC(hct_attention_bwd(ws + ba.qkv, ws + ba.o, d_o, (const float*)(ws + ba.lse), B, N, heads, d / heads, p->dt, dqkv, s));
+  RC(linear_wgrad(p, dqkv, ws + ba.x1, M, 3 * d, d, bp.qkv_w, bp.qkv_b, s));
+  RC(linear_dgrad(p, dqkv, M, 3 * d, bp.qkv_w, d, dx, HCT_ACT_NONE, nullptr, s));
+  RC(hct_layernorm_bwd(dx, p->dt, h_in, (const float*)(ws + ba.mean1), (const float*)(ws + ba.rstd1), p->pf(bp.ln1_w), dh, M, d,
+                       dh, dhs, p->dt, p->gf(bp.ln1_w), p->gf(bp.ln1_b), prev_fc2_b >= 0 ? p->gf(prev_fc2_b) : nullptr, small,
+                       p->s_small_bytes, s));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int compute_dtype) {
+  if (!c || batch <= 0 || (compute_dtype != HCT_F32 && compute_dtype != HCT_BF16)) { set_error("hct_mae_plan_create: bad arguments"); return nullptr; }
+  if (c->patch_size <= 0 || c->input_size % c->patch_size || c->patch_size % 4) { set_error("hct_mae_plan_create: input_size %% patch_size != 0 or patch_size %% 4 != 0"); return nullptr; }
+  if (c->encoder_embed_dim % c->encoder_num_heads || c->decoder_embed_dim % c->decoder_num_heads) { set_error("hidden size should be divisible by num_heads"); return nullptr; }
+  if (c->encoder_embed_dim % 4 || c->decoder_embed_dim % 4 || c->encoder_mlp_dim % 4 || c->decoder_mlp_dim % 4) { set_error("embed/mlp dims must be multiples of 4"); return nullptr; }
+  hct_mae_plan* p = new hct_mae_plan();
+  p->cfg = *c;
+  p->B = batch; p->dt = compute_dtype;
+  p->g = c->input_size / c->patch_size;
+  p->L = p->g * p->g * p->g;
+  p->K = (int)((double)p->L * (1.0 - (double)c->mask_ratio));  // int(L * (1 - mask_ratio)), mae.py:205
+  p->pd = c->in_chans * c->patch_size * c->patch_size * c->patch_size;
+  p->Ne = p->K + 1; p->Nd = p->L + 1;
+  p->Me = batch * p->Ne; p->Md = batch * p->Nd;
+  p->D = c->encoder_embed_dim; p->Dd = c->decoder_embed_dim;
+  p->Mlp = c->encoder_mlp_dim; p->Mlpd = c->decoder_mlp_dim;
+  p->H = c->encoder_num_heads; p->Hd = c->decoder_num_heads;
+  if (p->K < 1) { set_error("mask_ratio leaves no visible patches"); delete p; return nullptr; }
+  const bool ub = c->use_bias != 0;
+  const int P = c->patch_size, C = c->in_chans;
+  // ---- parameters, forward-use order ----
+  std::vector<std::pair<int64_t, int64_t>> seg;  // per group [begin,end)
+  int64_t g0 = p->param_elems;
+  p->p_pe_w = add_param(p, "patch_embedding.patch_embeddings.weight", {p->D, C, P, P, P}, true, true, false);
+  p->p_pe_b = add_param(p, "patch_embedding.patch_embeddings.bias", {p->D}, true, false, false);
+  p->p_pos = c->pos_embed ? add_param(p, "patch_embedding.position_embeddings", {1, p->L, p->D}, true, false, false) : -1;
+  p->p_cls = add_param(p, "cls_token", {1, 1, p->D}, true, false, false);
+  seg.push_back({g0, p->param_elems});
+  for (int i = 0; i < c->encoder_depth; ++i) {
+    g0 = p->param_elems;
+    p->enc.push_back(add_block(p, "blocks." + std::to_string(i), p->D, p->Mlp, ub));
+    seg.push_back({g0, p->param_elems});
+  }
+  g0 = p->param_elems;
+  p->p_norm_w = add_param(p, "norm.weight", {p->D}, true, false, false);
+  p->p_norm_b = add_param(p, "norm.bias", {p->D}, true, false, false);
+  p->p_de_w = add_param(p, "decoder_embed.weight", {p->Dd, p->D}, true, true, true);
+  p->p_de_b = ub ? add_param(p, "decoder_embed.bias", {p->Dd}, true, false, false) : -1;
+  p->p_mask = add_param(p, "mask_token", {1, 1, p->Dd}, true, false, false);
+  p->p_dcls = add_param(p, "decoder_cls_token", {1, 1, p->Dd}, true, false, false);
+  p->p_dpos = add_param(p, "decoder_pos_embed", {1, p->L, p->Dd}, false, false, false);  // mae.py:92 frozen
+  seg.push_back({g0, p->param_elems});
+  for (int i = 0; i < c->decoder_depth; ++i) {
+    g0 = p->param_elems;
+    p->dec.push_back(add_block(p, "decoder_blocks." + std::to_string(i), p->Dd, p->Mlpd, ub));
+    seg.push_back({g0, p->param_elems});
+  }
+  g0 = p->param_elems;
+  p->p_dnorm_w = add_param(p, "decoder_norm.weight", {p->Dd}, true, false, false);
+  p->p_dnorm_b = add_param(p, "decoder_norm.bias", {p->Dd}, true, false, false);
+  p->p_pred_w = add_param(p, "decoder_pred.weight", {p->pd, p->Dd}, true, true, true);
+  p->p_pred_b = ub ? add_param(p, "decoder_pred.bias", {p->pd}, true, false, false) : -1;
+  seg.push_back({g0, p->param_elems});
+  // backward stages complete the groups in reverse
+  for (int i = (int)seg.size() - 1; i >= 0; --i) p->stage_range.push_back(seg[i]);
+
+  // ---- workspace ----
+  WsAlloc w;
+  const size_t es = p->esz();
+  const size_t B = batch, L = p->L, K = p->K, Me = p->Me, Md = p->Md, D = p->D, Dd = p->Dd;
+  p->a_ids_restore = w.take(B * L * 4);
+  p->a_ids_shuffle = w.take(B * L * 4);
+  p->a_mask = w.take(B * L * 4);
+  p->a_row_loss = w.take(B * L * 4);
+  p->a_patches = w.take(B * K * p->pd * es);
+  p->a_tok = w.take(B * K * D * es);
+  for (int i = 0; i <= c->encoder_depth; ++i) p->h_enc.push_back(w.take(Me * D * 4));
+  for (int i = 0; i < c->encoder_depth; ++i) p->aenc.push_back(alloc_block(w, Me, D, p->Mlp, (size_t)batch * p->H * p->Ne, es));
+  p->a_latent = w.take(Me * D * es);
+  p->a_lat_mean = w.take(Me * 4);
+  p->a_lat_rstd = w.take(Me * 4);
+  p->a_e = w.take(Me * Dd * es);
+  for (int i = 0; i <= c->decoder_depth; ++i) p->h_dec.push_back(w.take(Md * Dd * 4));
+  for (int i = 0; i < c->decoder_depth; ++i) p->adec.push_back(alloc_block(w, Md, Dd, p->Mlpd, (size_t)batch * p->Hd * p->Nd, es));
+  p->a_ynorm = w.take(Md * Dd * es);
+  p->a_yn_mean = w.take(Md * 4);
+  p->a_yn_rstd = w.take(Md * 4);
+  p->a_pred = w.take(Md * p->pd * es);
+  p->a_dpred = w.take(Md * p->pd * es);
+  const size_t Mx = Md > Me ? Md : Me, Dx = Dd > D ? Dd : D;
+  const size_t mlpx = (size_t)(p->Mlp > p->Mlpd ? p->Mlp : p->Mlpd);
+  p->s_dh = w.take(Mx * Dx * 4);
+  p->s_dh_shadow = w.take(Mx * Dx * es);
+  p->s_dbig = w.take(Mx * mlpx * es);
+  p->s_dx = w.take(Mx * Dx * es);
+  p->s_do = w.take(Mx * Dx * es);
+  p->s_dqkv = w.take(Mx * 3 * Dx * es);
+  size_t small = hct_layernorm_bwd_workspace_bytes((int)Mx, (int)Dx);
+  small = std::max(small, hct_assemble_bwd_workspace_bytes((int)Dx));
+  small = std::max(small, hct_colsum_workspace_bytes((int)Mx, (int)(3 * Dx)));
+  small = std::max(small, hct_colsum_workspace_bytes((int)Mx, (int)mlpx));
+  small = std::max(small, hct_colsum_workspace_bytes((int)Md, p->pd));
+  p->s_small_bytes = small;
+  p->s_small = w.take(small);
+  size_t gw = 0;
+  for (int side = 0; side < 2; ++side) {
+    const int M = side ? p->Md : p->Me, d = side ? p->Dd : p->D, m = side ? p->Mlpd : p->Mlp;
+    gw = std::max(gw, wgrad_ws(p->dt, M, d, m));
+    gw = std::max(gw, wgrad_ws(p->dt, M, m, d));
+    gw = std::max(gw, wgrad_ws(p->dt, M, d, d));
+    gw = std::max(gw, wgrad_ws(p->dt, M, 3 * d, d));
+  }
+  gw = std::max(gw, wgrad_ws(p->dt, p->Md, p->pd, p->Dd));
+  gw = std::max(gw, wgrad_ws(p->dt, p->Me, p->Dd, p->D));
+  gw = std::max(gw, wgrad_ws(p->dt, batch * p->K, p->D, p->pd));
+  p->s_gemm_bytes = gw;
+  p->s_gemm = w.take(gw);
+  p->ws_bytes = w.cur;
+
+  // ---- named activations (parity tests) ----
+  auto reg = [&](const std::string& n, size_t off, int64_t r, int64_t cc, int dtp) { p->acts[n] = Act{off, r, cc, dtp}; };
+  reg("ids_restore", p->a_ids_restore, batch, p->L, 2);
+  reg("ids_shuffle", p->a_ids_shuffle, batch, p->L, 2);
+  reg("mask", p->a_mask, batch, p->L, HCT_F32);
+  reg("patches", p->a_patches, (int64_t)batch * p->K, p->pd, p->dt);
+  reg("tok", p->a_tok, (int64_t)batch * p->K, p->D, p->dt);
+  reg("enc_in", p->h_enc[0], p->Me, p->D, HCT_F32);
+  for (int i = 0; i < c->encoder_depth; ++i) reg("enc" + std::to_string(i) + ".out", p->h_enc[i + 1], p->Me, p->D, HCT_F32);
+  reg("latent", p->a_latent, p->Me, p->D, p->dt);
+  reg("dec_in", p->h_dec[0], p->Md, p->Dd, HCT_F32);
+  for (int i = 0; i < c->decoder_depth; ++i) reg("dec" + std::to_string(i) + ".out", p->h_dec[i + 1], p->Md, p->Dd, HCT_F32);
+  reg("pred_full", p->a_pred, p->Md, p->pd, p->dt);
+  reg("dpred_full", p->a_dpred, p->Md, p->pd, p->dt);
+  if (c->encoder_depth > 0) {
+    reg("enc0.qkv", p->aenc[0].qkv, p->Me, 3 * p->D, p->dt);
+    reg("enc0.attn_o", p->aenc[0].o, p->Me, p->D, p->dt);
+  }
+  return p;
+}
+
+void hct_mae_plan_destroy(hct_mae_plan* p) { delete p; }
+int hct_mae_plan_num_params(const hct_mae_plan* p) { return (int)p->params.size(); }
+int hct_mae_plan_param_info(const hct_mae_plan* p, int index, hct_param_info* out) {
+  HCT_REQUIRE(p && out && index >= 0 && index < (int)p->params.size(), "hct_mae_plan_param_info: bad index");
+  *out = p->params[index];
+  return 0;
+}
+int64_t hct_mae_plan_param_elems(const hct_mae_plan* p) { return p->param_elems; }
+int64_t hct_mae_plan_bf16_t_elems(const hct_mae_plan* p) { return p->bf16t_elems; }
+size_t hct_mae_plan_workspace_bytes(const hct_mae_plan* p) { return p->ws_bytes; }
+
+int hct_mae_plan_bind(hct_mae_plan* p, float* params, float* grads, void* params_bf16, void* params_bf16_t, void* workspace,
+                      size_t workspace_bytes) {
+  HCT_REQUIRE(p && params && workspace, "hct_mae_plan_bind: null buffer");
+  HCT_REQUIRE(p->dt == HCT_F32 || (params_bf16 && params_bf16_t), "hct_mae_plan_bind: bf16 mode needs the bf16 weight buffers");
+  if (workspace_bytes < p->ws_bytes) { set_error("hct_mae_plan_bind: workspace too small"); return HCT_E_WORKSPACE; }
+  p->params_f32 = params; p->grads = grads;
+  p->params_bf16 = (bf16*)params_bf16; p->params_bf16_t = (bf16*)params_bf16_t;
+  p->ws = (unsigned char*)workspace;
+  p->fwd_done = false;
+  return 0;
+}
+
+int hct_mae_refresh_weights(hct_mae_plan* p, int with_plain, void* stream) {
+  HCT_REQUIRE(p && p->params_f32, "hct_mae_refresh_weights: plan not bound");
+  if (p->dt != HCT_BF16) return 0;
+  if (with_plain) RC(hct_cast(p->params_f32, HCT_F32, p->params_bf16, HCT_BF16, p->param_elems, stream));
+  for (const auto& pi : p->params) {
+    if (pi.bf16_t_offset < 0) continue;
+    const int rows = (int)pi.shape[0], cols = (int)(pi.numel / pi.shape[0]);
+    RC(hct_transpose_cast(p->params_f32 + pi.offset, HCT_F32, p->params_bf16_t + pi.bf16_t_offset, HCT_BF16, rows, cols, stream));
+  }
+  return 0;
+}
+
+int hct_mae_forward(hct_mae_plan* p, const float* x, const float* noise, float* loss, void* stream) {
+  HCT_REQUIRE(p && p->ws && x && noise && loss, "hct_mae_forward: plan not bound or null argument");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned char* ws = p->ws;
+  const hct_mae_config& c = p->cfg;
+  const int B = p->B;
+  int32_t* ids_restore = (int32_t*)(ws + p->a_ids_restore);
+  int32_t* ids_shuffle = (int32_t*)(ws + p->a_ids_shuffle);
+  float* mask = (float*)(ws + p->a_mask);
+  RC(hct_mask_rank(noise, B, p->L, p->K, ids_restore, ids_shuffle, mask, s));
+  RC(hct_patch_gather(x, ids_shuffle, B, c.in_chans, c.input_size, c.patch_size, p->L, p->K, ws + p->a_patches, p->dt, s));
+  RC(linear_fwd(p, ws + p->a_patches, B * p->K, p->pd, p->p_pe_w, p->p_pe_b, p->D, ws + p->a_tok, p->dt, HCT_ACT_NONE, nullptr, nullptr, s));
+  RC(hct_encoder_assemble_fwd(ws + p->a_tok, p->dt, p->pf(p->p_cls), p->pf(p->p_pos), ids_shuffle, B, p->L, p->K, p->D, (float*)(ws + p->h_enc[0]), s));
+  for (int i = 0; i < c.encoder_depth; ++i)
+    RC(block_forward(p, p->enc[i], p->aenc[i], (const float*)(ws + p->h_enc[i]), (float*)(ws + p->h_enc[i + 1]), B, p->Ne, p->D, p->Mlp, p->H, s));
+  RC(hct_layernorm_fwd((const float*)(ws + p->h_enc[c.encoder_depth]), p->pf(p->p_norm_w), p->pf(p->p_norm_b), p->Me, p->D, 1e-5f,
+                       ws + p->a_latent, p->dt, (float*)(ws + p->a_lat_mean), (float*)(ws + p->a_lat_rstd), s));
+  RC(linear_fwd(p, ws + p->a_latent, p->Me, p->D, p->p_de_w, p->p_de_b, p->Dd, ws + p->a_e, p->dt, HCT_ACT_NONE, nullptr, nullptr, s));
+  RC(hct_decoder_assemble_fwd(ws + p->a_e, p->dt, p->pf(p->p_mask), p->pf(p->p_dcls), p->pf(p->p_dpos), ids_restore, B, p->L, p->K, p->Dd,
+                              (float*)(ws + p->h_dec[0]), s));
+  for (int i = 0; i < c.decoder_depth; ++i)
+    RC(block_forward(p, p->dec[i], p->adec[i], (const float*)(ws + p->h_dec[i]), (float*)(ws + p->h_dec[i + 1]), B, p->Nd, p->Dd, p->Mlpd, p->Hd, s));
+  RC(hct_layernorm_fwd((const float*)(ws + p->h_dec[c.decoder_depth]), p->pf(p->p_dnorm_w), p->pf(p->p_dnorm_b), p->Md, p->Dd, 1e-5f,
+                       ws + p->a_ynorm, p->dt, (float*)(ws + p->a_yn_mean), (float*)(ws + p->a_yn_rstd), s));
+  RC(linear_fwd(p, ws + p->a_ynorm, p->Md, p->Dd, p->p_pred_w, p->p_pred_b, p->pd, ws + p->a_pred, p->dt, HCT_ACT_NONE, nullptr, nullptr, s));
+  RC(hct_masked_mse(ws + p->a_pred, p->dt, x, mask, B, c.in_chans, c.input_size, c.patch_size, c.norm_pix_loss,
+                    (float)((int64_t)B * (p->L - p->K)), (float*)(ws + p->a_row_loss), loss, nullptr, nullptr, s));
+  p->fwd_done = true;
+  return 0;
+}
+
+int hct_mae_set_loss_grad(hct_mae_plan* p, const float* dloss) {
+  HCT_REQUIRE(p, "hct_mae_set_loss_grad: null plan");
+  p->dloss = dloss;
+  return 0;
+}
+
+int hct_mae_num_backward_stages(const hct_mae_plan* p) { return (int)p->stage_range.size(); }
+int hct_mae_backward_stage_range(const hct_mae_plan* p, int stage, int64_t* begin, int64_t* end) {
+  HCT_REQUIRE(p && stage >= 0 && stage < (int)p->stage_range.size(), "hct_mae_backward_stage_range: bad stage");
+  *begin = p->stage_range[stage].first;
+  *end = p->stage_range[stage].second;
+  return 0;
+}
+
+int hct_mae_backward_stage(hct_mae_plan* p, int stage, const float* x, void* stream) {
+  HCT_REQUIRE(p && p->ws && p->grads, "hct_mae_backward_stage: plan not bound (or no gradient buffer)");
+  if (!p->fwd_done) { set_error("hct_mae_backward_stage: forward has not run"); return HCT_E_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  unsigned char* ws = p->ws;
+  const hct_mae_config& c = p->cfg;
+  const int B = p->B;
+  const int nd = c.decoder_depth, ne = c.encoder_depth;
+  float* dh = (float*)(ws + p->s_dh);
+  void* dhs = ws + p->s_dh_shadow;
+  void* dx = ws + p->s_dx;
+  void* small = ws + p->s_small;
+  if (stage == 0) {  // loss seed -> decoder_pred -> decoder_norm
+    HCT_REQUIRE(x, "hct_mae_backward_stage: stage 0 needs the input volume");
+    RC(hct_masked_mse(ws + p->a_pred, p->dt, x, (const float*)(ws + p->a_mask), B, c.in_chans, c.input_size, c.patch_size, c.norm_pix_loss,
+                      (float)((int64_t)B * (p->L - p->K)), nullptr, nullptr, ws + p->a_dpred, p->dloss, s));
+    RC(linear_wgrad(p, ws + p->a_dpred, ws + p->a_ynorm, p->Md, p->pd, p->Dd, p->p_pred_w, p->p_pred_b, s));
+    RC(linear_dgrad(p, ws + p->a_dpred, p->Md, p->pd, p->p_pred_w, p->Dd, dx, HCT_ACT_NONE, nullptr, s));
+    RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + p->h_dec[nd]), (const float*)(ws + p->a_yn_mean), (const float*)(ws + p->a_yn_rstd),
+                         p->pf(p->p_dnorm_w), nullptr, p->Md, p->Dd, dh, dhs, p->dt, p->gf(p->p_dnorm_w), p->gf(p->p_dnorm_b),
+                         nd > 0 ? p->gf(p->dec[nd - 1].fc2_b) : nullptr, small, p->s_small_bytes, s));
+    return 0;
+  }
+  if (stage <= nd) {
+    const int i = nd - stage;
+    return block_backward(p, p->dec[i], p->adec[i], (const float*)(ws + p->h_dec[i]), B, p->Nd, p->Dd, p->Mlpd, p->Hd,
+                          i > 0 ? p->dec[i - 1].fc2_b : -1, s);
+  }
+  if (stage == nd + 1) {  // decoder input assembly -> decoder_embed -> encoder norm
+    void* de = ws + p->s_do;
+    RC(hct_decoder_assemble_bwd(dh, (const int32_t*)(ws + p->a_ids_restore), (const int32_t*)(ws + p->a_ids_shuffle), B, p->L, p->K, p->Dd, de,
+                                p->dt, p->gf(p->p_mask), p->gf(p->p_dcls), small, p->s_small_bytes, s));
+    RC(linear_wgrad(p, de, ws + p->a_latent, p->Me, p->Dd, p->D, p->p_de_w, p->p_de_b, s));
+    RC(linear_dgrad(p, de, p->Me, p->Dd, p->p_de_w, p->D, dx, HCT_ACT_NONE, nullptr, s));
+    RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + p->h_enc[ne]), (const float*)(ws + p->a_lat_mean), (const float*)(ws + p->a_lat_rstd),
+                         p->pf(p->p_norm_w), nullptr, p->Me, p->D, dh, dhs, p->dt, p->gf(p->p_norm_w), p->gf(p->p_norm_b),
+                         ne > 0 ? p->gf(p->enc[ne - 1].fc2_b) : nullptr, small, p->s_small_bytes, s));
+    return 0;
+  }
+  if (stage <= nd + 1 + ne) {
+    const int i = ne - (stage - nd - 1);
+    return block_backward(p, p->enc[i], p->aenc[i], (const float*)(ws + p->h_enc[i]), B, p->Ne, p->D, p->Mlp, p->H,
+                          i > 0 ? p->enc[i - 1].fc2_b : -1, s);
+  }
+  if (stage == nd + ne + 2) {  // encoder input assembly -> patch embedding
+    void* dtok = ws + p->s_do;
+    RC(hct_encoder_assemble_bwd(dh, (const int32_t*)(ws + p->a_ids_restore), B, p->L, p->K, p->D, dtok, p->dt, p->gf(p->p_cls),
+                                p->p_pos >= 0 ? p->gf(p->p_pos) : nullptr, small, p->s_small_bytes, s));
+    RC(linear_wgrad(p, dtok, ws + p->a_patches, B * p->K, p->D, p->pd, p->p_pe_w, p->p_pe_b, s));
+    return 0;
+  }
+  set_error("hct_mae_backward_stage: stage %d out of range", stage);
+  return HCT_E_BADARG;
+}
+
+const void* hct_mae_plan_activation(const hct_mae_plan* p, const char* name, int64_t* rows, int64_t* cols, int* dtype) {
+  if (!p || !p->ws || !name) return nullptr;
+  auto it = p->acts.find(name);
+  if (it == p->acts.end()) return nullptr;
+  if (rows) *rows = it->second.rows;
+  if (cols) *cols = it->second.cols;
+  if (dtype) *dtype = it->second.dtype;
+  return p->ws + it->second.off;
+}
+
+}  // extern "C"

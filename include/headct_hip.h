@@ -1,0 +1,243 @@
+/*
+ * headct_hip.h -- C ABI of libheadct_hip.so: the MI355X (gfx950) MAE pre-training hot path.
+ *
+ * The reference (nirvanesque/headCT_foundation) has no FFI seam: the hot path sits behind the
+ * Python nn.Module contract of MaskedAutoencoderViT and the engine_pretrain_mae functions
+ * (SURVEY.md 8b).  This header is the boundary a maintainer would bind instead of the PyTorch
+ * operators that path dispatches today; each entry point cites the reference lines it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all memory,
+ *     the library never allocates or frees device memory;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); calls are asynchronous;
+ *   - return value: 0 on success, a positive hipError_t, or a negative HCT_E_* code;
+ *     hct_last_error_string() gives text for the calling thread's last failure;
+ *   - dtype codes: HCT_F32 = 0 (fp32 storage), HCT_BF16 = 1 (bfloat16 storage, fp32 accumulation);
+ *   - matrices are row-major; "ld" = row stride in elements.
+ */
+#ifndef HEADCT_HIP_H
+#define HEADCT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HCT_F32 0
+#define HCT_BF16 1
+
+#define HCT_E_BADARG (-1)
+#define HCT_E_UNSUPPORTED (-2)
+#define HCT_E_WORKSPACE (-3)
+#define HCT_E_STATE (-4)
+
+#define HCT_ACT_NONE 0
+#define HCT_ACT_GELU 1  /* out = gelu_erf(acc + bias); aux (if given) receives the pre-activation */
+#define HCT_ACT_DGELU 2 /* out = acc * gelu_erf'(aux)   (aux = saved pre-activation)             */
+
+const char* hct_last_error_string(void);
+int hct_version(void);
+/* 1 when the tuned gfx950 MFMA kernels are compiled in (always, in this build). */
+int hct_has_mfma_kernels(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:  C = act(alpha * op(A) . op(B) + bias) (+ residual)
+ * Replaces nn.Linear / Conv3d-as-GEMM forward and the autograd dgrad / wgrad products
+ * (attentionblock.py:41-42,54,64; MONAI MLPBlock linear1/linear2; mae.py:118-119;
+ *  patch_embedding.py:102-105,149).
+ *   transA = 0: A stored [M,K];  transA = 1: A stored [K,M]  (op(A) = A^T)
+ *   transB = 1: B stored [N,K] (the nn.Linear weight layout, "NT"); transB = 0: B stored [K,N]
+ * Dispatch: bf16 x bf16, transA=0, transB=1, K%64==0, N%16==0 -> tuned MFMA "NT" kernel;
+ *           bf16 x bf16, transA=1, transB=0, M%16==0, N%16==0   -> tuned MFMA "TN" kernel (split-K
+ *           over the reduction, partial slabs in `workspace`, deterministic reduction);
+ *           anything else (all fp32 work) -> generic strided kernel (fp32 FMA accumulation).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hct_gemm_args {
+  int M, N, K;
+  const void* A; int a_dtype; int64_t lda; int transA;
+  const void* B; int b_dtype; int64_t ldb; int transB;
+  void* C; int c_dtype; int64_t ldc;
+  const float* bias;     /* [N] fp32 or NULL */
+  const float* residual; /* [M,N] fp32 (row stride ldr) or NULL; added after the activation */
+  int64_t ldr;
+  int act;               /* HCT_ACT_* */
+  void* aux; int aux_dtype; int64_t ldaux;
+  void* C2; int c2_dtype; int64_t ldc2; /* optional second copy of the output (e.g. bf16 shadow) */
+  float alpha;
+  int force_generic;     /* testing: always take the generic kernel */
+} hct_gemm_args;
+
+size_t hct_gemm_workspace_bytes(const hct_gemm_args* a);
+int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Random masking from supplied noise (mae.py:204-216).  Stable ranking: ties -> lower index first.
+ *   noise [B,L] fp32  ->  ids_restore [B,L] i32, ids_shuffle [B,L] i32 (first K = ids_keep),
+ *   mask [B,L] fp32 (0 keep, 1 masked).
+ * ------------------------------------------------------------------------------------------ */
+int hct_mask_rank(const float* noise, int B, int L, int K, int32_t* ids_restore, int32_t* ids_shuffle,
+                  float* mask, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Patch gather (im2col of the stride==kernel Conv3d, kept tokens only; patch_embedding.py:149-152
+ * + mae.py:212).   x [B,C,S,S,S] fp32 -> rows [B*K, C*P^3] in Conv3d weight order (c,ph,pw,pd).
+ * ------------------------------------------------------------------------------------------ */
+int hct_patch_gather(const float* x, const int32_t* ids_shuffle, int B, int C, int S, int P, int L, int K,
+                     void* rows, int rows_dtype, void* stream);
+
+/* Encoder input assembly: h0[b,0,:] = cls;  h0[b,1+j,:] = tok[b*K+j,:] + pos[ids_keep[b,j],:]
+ * (patch_embedding.py:155-156, mae.py:212,233-234).  pos may be NULL (pos_embed == "none").   */
+int hct_encoder_assemble_fwd(const void* tok, int tok_dtype, const float* cls, const float* pos,
+                             const int32_t* ids_shuffle, int B, int L, int K, int D, float* h0, void* stream);
+/* backward: dtok[b*K+j] = dh0[b,1+j]; dcls = sum_b dh0[b,0]; dpos[l] = sum_{b: l kept} dh0[b,1+rank]. */
+int hct_encoder_assemble_bwd(const float* dh0, const int32_t* ids_restore, int B, int L, int K, int D,
+                             void* dtok, int dtok_dtype, float* dcls, float* dpos, void* workspace,
+                             size_t workspace_bytes, void* stream);
+/* workspace for the *_assemble_bwd reductions */
+size_t hct_assemble_bwd_workspace_bytes(int D);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim, eps = 1e-5 (nn.LayerNorm default; attentionblock.py:92-93,
+ * mae.py:116-117).  x fp32 [rows,D] (the residual stream); y in y_dtype; mean/rstd saved fp32.
+ * ------------------------------------------------------------------------------------------ */
+int hct_layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int D, float eps,
+                      void* y, int y_dtype, float* mean, float* rstd, void* stream);
+/* dx_total = dres + LN'(dy)  written fp32 to dx (may alias dres) and, if dx_shadow != NULL, also
+ * in shadow_dtype.  dgamma/dbeta [D] fp32 (overwritten); if dcolsum != NULL it receives
+ * sum_rows(dx_total) [D] (the bias gradient of the Linear that produced this residual branch).
+ * workspace: hct_layernorm_bwd_workspace_bytes(rows, D).                                       */
+size_t hct_layernorm_bwd_workspace_bytes(int rows, int D);
+int hct_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
+                      const float* gamma, const float* dres, int rows, int D, float* dx, void* dx_shadow,
+                      int shadow_dtype, float* dgamma, float* dbeta, float* dcolsum, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head self-attention, no mask, scale dh^-1/2 (attentionblock.py:54-62,
+ * F.scaled_dot_product_attention).  qkv [B,N,3,H,dh] (the fused-QKV Linear output, as the
+ * reference views it :54); o [B,N,H*dh] (head-merged, as :62); lse [B,H,N] fp32 saved for backward.
+ * dtype = storage of qkv / o / do / dqkv.
+ * ------------------------------------------------------------------------------------------ */
+int hct_attention_fwd(const void* qkv, int B, int N, int H, int dh, int dtype, void* o, float* lse, void* stream);
+int hct_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, int B, int N, int H,
+                      int dh, int dtype, void* dqkv, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Decoder input assembly (mae.py:257-265):
+ *   y[b,0]   = e[b,0] + dec_cls
+ *   y[b,1+l] = (ids_restore[b,l] < K ? e[b,1+ids_restore[b,l]] : mask_token) + dec_pos[l]
+ * e [B,K+1,D] in e_dtype; y fp32 [B,L+1,D].
+ * backward: de (e_dtype) gather of dy; dmask_token = sum over masked rows; ddec_cls = sum_b dy[b,0].
+ * ------------------------------------------------------------------------------------------ */
+int hct_decoder_assemble_fwd(const void* e, int e_dtype, const float* mask_token, const float* dec_cls,
+                             const float* dec_pos, const int32_t* ids_restore, int B, int L, int K, int D,
+                             float* y, void* stream);
+int hct_decoder_assemble_bwd(const float* dy, const int32_t* ids_restore, const int32_t* ids_shuffle, int B,
+                             int L, int K, int D, void* de, int de_dtype, float* dmask_token, float* ddec_cls,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Masked-voxel MSE (mae.py:277-301) fused with patchify (mae.py:160-170) and its backward seed.
+ *   pred [B, L+1, pd] (row 0 of each volume = cls row, ignored; mae.py:273), pd = P^3*C (C fastest)
+ *   loss (1 fp32, overwritten) = sum_l mask*mean_k (pred-tgt)^2 / sum(mask)
+ *   dpred (may be NULL) same shape/dtype as pred: s*2*mask*(pred-tgt)/(pd*sum(mask)); 0 on cls/kept rows;
+ *   s = *dpred_scale (device fp32, the incoming dLoss, e.g. a GradScaler factor) or 1 if NULL.
+ *   loss may be NULL when only dpred is wanted.
+ *   norm_pix: per-patch (t-mean)/sqrt(var_unbiased+1e-6) target (mae.py:290-293).
+ *   mask_sum = sum(mask) (= B*(L-K) for masks from hct_mask_rank); row_loss: workspace of B*L floats.
+ * ------------------------------------------------------------------------------------------ */
+int hct_masked_mse(const void* pred, int pred_dtype, const float* x, const float* mask, int B, int C, int S,
+                   int P, int norm_pix, float mask_sum, float* row_loss, float* loss, void* dpred,
+                   const float* dpred_scale, void* stream);
+/* reconstructed voxels: unpatchify (mae.py:172-192). pred rows [B, L(+1 if has_cls_row), pd] -> [B,C,S,S,S] fp32 */
+int hct_unpatchify(const void* pred, int pred_dtype, int has_cls_row, int B, int C, int S, int P, float* vol,
+                   void* stream);
+
+/* Column sum of a [rows, cols] matrix -> fp32 [cols] (bias gradients). workspace >= hct_colsum_workspace_bytes. */
+size_t hct_colsum_workspace_bytes(int rows, int cols);
+int hct_colsum(const void* x, int dtype, int rows, int cols, int64_t ld, float* out, void* workspace,
+               size_t workspace_bytes, void* stream);
+
+/* dtype conversion / transposed conversion (bf16 working copies of the fp32 master weights). */
+int hct_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+int hct_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-parameter gradient clip (src/utils/misc.py:374-383) + AdamW (src/utils/optimizers.py:354-360
+ * -> torch.optim.AdamW defaults) over a FLAT fp32 parameter/gradient/state buffer described by a
+ * device segment table seg_off[nseg+1] (element offsets; segment i = [seg_off[i], seg_off[i+1])).
+ *   hct_grad_norms : norms[i] = ||g_i||_2 ; coef[i] = clip/(norm+1e-6) if < 1 else 1 (clip <= 0: all 1).
+ *                    scale_in_place != 0 also multiplies the gradients (the reference's in-place form).
+ *   hct_adamw_step : g <- g*coef (written back), decoupled weight decay on every element, bias-corrected
+ *                    update; `step` is 1-based; optionally refreshes a bf16 shadow of the parameters.
+ *                    skip[i] != 0 freezes segment i (requires_grad = False).
+ * ------------------------------------------------------------------------------------------ */
+size_t hct_grad_norms_workspace_bytes(int64_t total);
+int hct_grad_norms(float* grads, const int64_t* seg_off, int nseg, int64_t total, float clip, int scale_in_place,
+                   float* norms, float* coef, void* workspace, size_t workspace_bytes, void* stream);
+int hct_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* seg_off,
+                   const float* coef, const uint8_t* skip, int nseg, int64_t total, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, void* params_bf16, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-model driver (MaskedAutoencoderViT.forward mae.py:303-317 and its autograd backward,
+ * engine_pretrain_mae.py:58-62).  The plan is a HOST object describing the parameter layout
+ * (names / shapes / offsets into one flat buffer, in the reference's registration order) and the
+ * activation workspace layout for a fixed batch size; it owns no device memory.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hct_mae_config {
+  int input_size, patch_size, in_chans;
+  float mask_ratio;
+  int pos_embed; /* 0 none, 1 learnable, 2 sincos (same storage; init differs on the host) */
+  int encoder_depth, encoder_embed_dim, encoder_mlp_dim, encoder_num_heads;
+  int decoder_depth, decoder_embed_dim, decoder_mlp_dim, decoder_num_heads;
+  int norm_pix_loss, use_bias;
+} hct_mae_config;
+
+typedef struct hct_mae_plan hct_mae_plan;
+
+typedef struct hct_param_info {
+  char name[96];
+  int ndim;
+  int64_t shape[5];
+  int64_t offset; /* element offset into the flat fp32 parameter / gradient buffers */
+  int64_t numel;
+  int requires_grad;
+  int is_matrix;      /* 1: a GEMM weight that gets bf16 (+ transposed bf16) working copies */
+  int64_t bf16_t_offset; /* element offset of the transposed bf16 copy in the bf16-T buffer, or -1 */
+} hct_param_info;
+
+/* compute_dtype: HCT_F32 (parity mode: every kernel fp32) or HCT_BF16 (bf16 storage + MFMA). */
+hct_mae_plan* hct_mae_plan_create(const hct_mae_config* cfg, int batch, int compute_dtype);
+void hct_mae_plan_destroy(hct_mae_plan*);
+int hct_mae_plan_num_params(const hct_mae_plan*);
+int hct_mae_plan_param_info(const hct_mae_plan*, int index, hct_param_info* out);
+int64_t hct_mae_plan_param_elems(const hct_mae_plan*);     /* flat fp32 params / grads length (padded) */
+int64_t hct_mae_plan_bf16_t_elems(const hct_mae_plan*);    /* transposed-bf16 weight buffer length      */
+size_t hct_mae_plan_workspace_bytes(const hct_mae_plan*);  /* activations + scratch                      */
+/* bind caller-owned device buffers. params_bf16 / params_bf16_t may be NULL in HCT_F32 mode. */
+int hct_mae_plan_bind(hct_mae_plan*, float* params, float* grads, void* params_bf16, void* params_bf16_t,
+                      void* workspace, size_t workspace_bytes);
+/* refresh bf16 + transposed-bf16 working copies from the fp32 master weights (after load / optimizer step).
+ * with_plain = 0 skips the plain bf16 copy (hct_adamw_step already wrote it). */
+int hct_mae_refresh_weights(hct_mae_plan*, int with_plain, void* stream);
+/* forward: x [B,C,S,S,S] fp32, noise [B,L] fp32 -> *loss (device fp32). Saves activations in the workspace. */
+int hct_mae_forward(hct_mae_plan*, const float* x, const float* noise, float* loss, void* stream);
+/* device pointer to the scalar dLoss that seeds the backward (NULL = 1.0). */
+int hct_mae_set_loss_grad(hct_mae_plan*, const float* dloss);
+/* backward in stages so the host can launch the per-bucket gradient all-reduce between them:
+ * stage 0 .. hct_mae_num_backward_stages()-1, in order; each stage finishes the gradients of the
+ * parameter range reported by hct_mae_backward_stage_range (element offsets into the flat buffer). */
+int hct_mae_num_backward_stages(const hct_mae_plan*);
+int hct_mae_backward_stage_range(const hct_mae_plan*, int stage, int64_t* begin, int64_t* end);
+int hct_mae_backward_stage(hct_mae_plan*, int stage, const float* x, void* stream);
+/* named activation lookup for parity tests: returns device pointer + shape/dtype, or NULL. */
+const void* hct_mae_plan_activation(const hct_mae_plan*, const char* name, int64_t* rows, int64_t* cols, int* dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEADCT_HIP_H */
