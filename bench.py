@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Benchmark: CT-volumes/s of one full MAE pre-training step (BASELINE.json metric / config #2).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" = zero_grad -> forward -> backward (+ bucketed RCCL gradient all-reduce for N > 1) -> per-parameter
+clip (3.0) -> AdamW -> cosine-warmup LR step, on one batch of synthetic 96^3 x 1ch volumes already resident in
+HBM (engine_pretrain_mae.py:52-71).  ViT-B/16^3, mask 0.75, bf16 storage + MFMA with fp32 accumulation, fp32
+master weights, B = 256 per GPU (weak scaling).  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     -- dominant kernel (the bf16 MFMA "NT" GEMM): algorithmic FLOPs of its launches / their summed
+                  duration, from HIP events recorded on the launch stream inside the timed region
+                  (csrc/prof.hip); peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).
+  cpu_baseline -- the CPU oracle's train step (oracle/mae_oracle.py, plain PyTorch fp32) timed on this host's
+                  cores on a bounded sample (ViT-B, B=8, a few steps), rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+VITB = dict(input_size=96, patch_size=16, mask_ratio=0.75, in_chans=1, dropout_rate=0.0, spatial_dims=3, patch_embed="conv",
+            pos_embed="sincos", encoder_depth=12, encoder_embed_dim=768, encoder_mlp_dim=3072, encoder_num_heads=12,
+            decoder_depth=8, decoder_embed_dim=768, decoder_mlp_dim=3072, decoder_num_heads=16, norm_pix_loss=False, use_bias=False)
+
+
+def algorithmic_train_flops_per_volume(c) -> float:
+    """multiply-add = 2; GEMMs + QK^T + PV; patch-embed on kept tokens; train step = 3 x forward."""
+    L = (c["input_size"] // c["patch_size"]) ** 3
+    K = int(L * (1 - c["mask_ratio"]))
+    pd = c["in_chans"] * c["patch_size"] ** 3
+    D, M, Dd, Md = c["encoder_embed_dim"], c["encoder_mlp_dim"], c["decoder_embed_dim"], c["decoder_mlp_dim"]
+    blk = lambda N, d, m: N * (8 * d * d + 4 * d * m) + 4 * N * N * d
+    fwd = 2.0 * K * pd * D + c["encoder_depth"] * blk(K + 1, D, M) + 2.0 * (K + 1) * D * Dd + c["decoder_depth"] * blk(L + 1, Dd, Md) + 2.0 * L * Dd * pd
+    return 3.0 * fwd
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    """Oracle train step on the host cores: ViT-B, B=8 (SURVEY 8d / BASELINE.md 3).  Bounded sample."""
+    from oracle import mae_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = O.CONFIGS["vitb"]
+    B = 8
+    st = O.TrainState(O.make_params(cfg, 42, generic=False))
+    hp = dict(base_lr=1.5e-4 * B / 256, min_lr=1.5e-7, warmup=2, total=100, weight_decay=5e-3, grad_clip=3.0)
+    x, noise = O.make_volume(cfg, B, 42), O.make_noise(cfg, B, 42)
+    times = []
+    t_start = time.time()
+    for i in range(8):
+        t0 = time.time()
+        O.train_step(cfg, st, x, noise, **hp)
+        dt = time.time() - t0
+        if i >= 1:
+            times.append(dt)
+        if time.time() - t_start > seconds_budget and len(times) >= 2:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(B / med, 3), "unit": "CT-volumes/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/mae_oracle.py train_step, ViT-B/16^3 96^3x1ch fp32, B={B}, median of {len(times)} steps after 1 warm-up "
+                      f"({med:.2f} s/step); host has {os.cpu_count()} logical cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="volumes per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket the dominant kernel with HIP events")
+    ap.add_argument("--bucket-mb", type=float, default=64.0)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from headct_foundation_amd import MaskedAutoencoderViT, _lib
+    from headct_foundation_amd.ddp import DistributedDataParallel
+    from headct_foundation_amd.lr_sched import get_cosine_schedule_with_warmup
+    from headct_foundation_amd.optim import HipAdamW, clip_gradients
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    lib = _lib.load()
+    B, G = args.batch, world
+    torch.manual_seed(42)  # reference init scheme at seed 42 (same weights on every rank; DDP broadcasts rank 0's anyway)
+    model = MaskedAutoencoderViT(**VITB, compute_dtype=args.dtype).to(device)
+    ddp = DistributedDataParallel(model, device_ids=[device], bucket_cap_mb=args.bucket_mb) if world > 1 else model
+    total_steps = max(1000, args.steps + args.warmup)
+    base_lr = 1.5e-4 * B * G / 256  # main_pretrain_mae.py:149-151
+    opt = HipAdamW(ddp, lr=base_lr, weight_decay=5e-3, betas=(0.9, 0.95))
+    sched = get_cosine_schedule_with_warmup(opt, int(0.05 * total_steps), total_steps, lr_end=base_lr * 1e-3)
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(42 + rank)  # main_pretrain_mae.py:213
+    pool = [torch.rand(B, 1, 96, 96, 96, device=device, generator=gen) for _ in range(4)]
+    noises = [torch.rand(B, model.num_patches, device=device, generator=gen) for _ in range(4)]
+    losses = torch.zeros(args.steps + args.warmup, device=device)
+
+    def step(i):
+        opt.zero_grad()
+        loss, _, _ = ddp(pool[i % 4], noise=noises[i % 4])
+        loss.backward()
+        clip_gradients(ddp, 3.0)
+        opt.step()
+        sched.step()
+        losses[i] = loss.detach()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    prof = not args.no_prof
+    if prof:
+        lib.hct_prof_reset()
+        lib.hct_prof_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if prof:
+        lib.hct_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    lv = losses.cpu()
+    if not torch.isfinite(lv).all():
+        raise SystemExit(f"non-finite loss during the benchmark: {lv.tolist()}")
+
+    roof = None
+    if prof:
+        ms, n, w = C.c_double(), C.c_int64(), C.c_double()
+        _lib.check(lib.hct_prof_read(0, C.byref(ms), C.byref(n), C.byref(w)), "hct_prof_read")
+        if n.value and ms.value > 0:
+            ach = w.value / (ms.value * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": n.value // args.steps, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+                    "time_share_of_step": round(ms.value * 1e-3 / elapsed, 4)}
+        extra = {}
+        for kid, name in ((1, "gemm_bf16_tn_kernel"), (3, "attention_fwd"), (4, "attention_bwd"), (2, "gemm_generic")):
+            _lib.check(lib.hct_prof_read(kid, C.byref(ms), C.byref(n), C.byref(w)), "hct_prof_read")
+            if n.value and ms.value > 0:
+                extra[name] = {"TFLOP/s": round(w.value / (ms.value * 1e-3) / 1e12, 2), "time_share_of_step": round(ms.value * 1e-3 / elapsed, 4)}
+        lib.hct_prof_reset()
+    if rank == 0:
+        vols = B * G * args.steps
+        flops_vol = algorithmic_train_flops_per_volume(VITB)
+        out = {
+            "metric": "CT-volumes/sec MAE pretrain step (96^3, ViT-B/16^3, mask 0.75)",
+            "value": round(vols / elapsed, 2), "unit": "CT-volumes/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE config #2: MAE ViT-B/16^3, 96^3x1ch, mask 0.75, full train step (fwd+bwd+clip+AdamW+LR)",
+                       "per_gpu_batch": B, "global_batch": B * G, "parallelism": f"dp{G}", "init": "reference init, seed 42",
+                       "algorithmic_GFLOP_per_volume": round(flops_vol / 1e9, 2)},
+            "step_mfma_frac": round(vols / elapsed * flops_vol / G / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "roofline": roof, "loss_first": round(float(lv[0]), 5), "loss_last": round(float(lv[-1]), 5),
+        }
+        if prof and extra:
+            out["other_kernels"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,331 @@
-// bf16 MFMA attention (placeholder until the LDS-resident MFMA kernels land; dispatcher falls back to simple).
+// bf16 MFMA attention for the MAE token counts (55 / 217 / 129 / 513 tokens, head dim 48 / 64): the whole K and V
+// (forward) or Q, K, V, dO (backward) of one (batch, head) live in LDS, so there is no K/V re-streaming.
+//
+// LDS image (shared by all four operands): row = token, 128 B = 64 bf16 per row (head dim zero-padded to 64),
+// 16-B chunk c of row r stored at chunk  c ^ ((r>>1)&7)  -> the b128 row reads of the MFMA A/B operands are
+// bank-conflict-free; column ("transposed") operands come from the same image with ds_read_b64_tr_b16.
+//
+// forward  (4 waves, wave = 16-query tile, online softmax over 32-key steps):
+//     S^T = K.Q^T  (key on the accumulator row, query on the lane)  -> P^T feeds O^T = V^T.P^T directly as the
+//     B operand (accumulator-as-operand, no LDS round trip); V^T fragments by transposed reads.
+// backward (8 waves, no atomics, deterministic): every wave first owns 16-key tiles (dK, dV: loops query pairs,
+//     S = Q.K^T, dP = dO.V^T, dV^T += dO^T.P, dK^T += Q^T.dS), then owns 16-query tiles (dQ: loops key pairs,
+//     S^T, dP^T recomputed, dQ^T += K^T.dS^T).  7 MFMA products instead of 5; attention is ~3 % of the step's
+//     FLOPs, so the recompute is cheaper than cross-wave reductions.
 #include "common.h"
+
 namespace hct {
-bool attention_mfma_supported(int N, int H, int dh) { (void)N; (void)H; (void)dh; return false; }
-int attention_fwd_mfma(const void*, int, int, int, int, void*, float*, hipStream_t) { set_error("mfma attention not built"); return HCT_E_UNSUPPORTED; }
-int attention_bwd_mfma(const void*, const void*, const void*, const float*, int, int, int, int, void*, hipStream_t) { set_error("mfma attention not built"); return HCT_E_UNSUPPORTED; }
+
+namespace {
+
+constexpr int kRowBytes = 128;
+
+__device__ __forceinline__ int img_off(int r, int c) { return r * kRowBytes + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// cooperative load of one operand image: rows [0,N) x DH columns from global (row stride rs elements), zero pad
+template <int DH>
+__device__ __forceinline__ void load_image(unsigned char* img, const bf16* __restrict__ g, int64_t rs, int N, int Npad,
+                                           int nthreads) {
+  for (int idx = threadIdx.x; idx < Npad * 8; idx += nthreads) {
+    const int r = idx >> 3, c = idx & 7;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < N && c * 8 < DH) v = *reinterpret_cast<const bf16x8*>(g + (int64_t)r * rs + c * 8);
+    *reinterpret_cast<bf16x8*>(img + img_off(r, c)) = v;
+  }
+}
+
+// operand with its row index on lane&15 and 8 consecutive d (k-step ks) per lane
+__device__ __forceinline__ bf16x8 frag_row(const unsigned char* img, int r0, int ks, int lane) {
+  const int r = r0 + (lane & 15), c = ks * 4 + (lane >> 4);
+  return *reinterpret_cast<const bf16x8*>(img + img_off(r, c));
+}
+
+// operand with column d0 + (lane&15) on the lane and 8 ROWS per lane: rows rA + 4g + {0..3}, rB + 4g + {0..3}
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* img, int rA, int rB, int d0, int lane) {
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  const int c = (d0 >> 3) + (pp >> 1), sub = (pp & 1) * 8;
+  const unsigned char* pa = img + img_off(rA + 4 * g + qq, c) + sub;
+  const unsigned char* pb = img + img_off(rB + 4 * g + qq, c) + sub;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
+  bf16x8 v = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+  return v;
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+// ============================================================================================================
+template <int DH>
+__global__ void __launch_bounds__(256) attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int N, int H, int Npad,
+                                                            bf16* __restrict__ o, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Kimg = smem;
+  unsigned char* Vimg = smem + Npad * kRowBytes;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int64_t rs = (int64_t)3 * H * DH;
+  const bf16* qb = qkv + (int64_t)b * N * rs + h * DH;
+  load_image<DH>(Kimg, qb + H * DH, rs, N, Npad, 256);
+  load_image<DH>(Vimg, qb + 2 * H * DH, rs, N, Npad, 256);
+  __syncthreads();
+  const float scale = rsqrtf((float)DH);
+  const int g = lane >> 4;
+  constexpr int ND = DH / 16;
+  const int nqt = (N + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q = qt * 16 + (lane & 15);
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int d = ks * 32 + 8 * g;
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (q < N && d < DH) v = *reinterpret_cast<const bf16x8*>(qb + (int64_t)q * rs + d);
+      qf[ks] = v;
+    }
+    float m = -INFINITY, lsum = 0.f;
+    f32x4 oacc[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) oacc[dt] = f32x4{0, 0, 0, 0};
+    for (int s = 0; s < (Npad >> 5); ++s) {
+      const int k0 = s * 32;
+      f32x4 st0 = {0, 0, 0, 0}, st1 = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        st0 = MFMA(frag_row(Kimg, k0, ks, lane), qf[ks], st0);
+        st1 = MFMA(frag_row(Kimg, k0 + 16, ks, lane), qf[ks], st1);
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st0[r] = (k0 + 4 * g + r < N) ? st0[r] * scale : -INFINITY;
+        st1[r] = (k0 + 16 + 4 * g + r < N) ? st1[r] * scale : -INFINITY;
+        mx = fmaxf(mx, fmaxf(st0[r], st1[r]));
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(m, mx);
+      const float corr = __expf(m - mnew);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st0[r] = __expf(st0[r] - mnew);
+        st1[r] = __expf(st1[r] - mnew);
+        ps += st0[r] + st1[r];
+      }
+      lsum = lsum * corr + ps;
+      const bf16x8 pb = pack8(st0, st1);
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        oacc[dt] = oacc[dt] * corr;
+        oacc[dt] = MFMA(frag_tr(Vimg, k0, k0 + 16, dt * 16, lane), pb, oacc[dt]);
+      }
+      m = mnew;
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (q < N) {
+      const float inv = 1.0f / lsum;
+      bf16* orow = o + ((int64_t)b * N + q) * (H * DH) + h * DH + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) Vec4<bf16>::store(orow + dt * 16, oacc[dt] * inv);
+      if (g == 0) lse[(int64_t)bh * N + q] = m + __logf(lsum);
+    }
+  }
+}
+
+// ============================================================================================================
+template <int DH>
+__global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                            const bf16* __restrict__ d_o, const float* __restrict__ lse,
+                                                            int N, int H, int Npad, bf16* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Qimg = smem;
+  unsigned char* Kimg = Qimg + Npad * kRowBytes;
+  unsigned char* Vimg = Kimg + Npad * kRowBytes;
+  unsigned char* Dimg = Vimg + Npad * kRowBytes;  // dO
+  float* sLse = reinterpret_cast<float*>(Dimg + Npad * kRowBytes);
+  float* sDel = sLse + Npad;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int64_t rs = (int64_t)3 * H * DH;
+  const int64_t os = (int64_t)H * DH;
+  const bf16* qb = qkv + (int64_t)b * N * rs + h * DH;
+  const bf16* ob = o + (int64_t)b * N * os + h * DH;
+  const bf16* dob = d_o + (int64_t)b * N * os + h * DH;
+  load_image<DH>(Qimg, qb, rs, N, Npad, 512);
+  load_image<DH>(Kimg, qb + H * DH, rs, N, Npad, 512);
+  load_image<DH>(Vimg, qb + 2 * H * DH, rs, N, Npad, 512);
+  load_image<DH>(Dimg, dob, os, N, Npad, 512);
+  for (int r = threadIdx.x; r < Npad; r += 512) {
+    float dl = 0.f, L = INFINITY;  // padded query rows: p = exp(s - inf) = 0
+    if (r < N) {
+#pragma unroll
+      for (int c = 0; c < DH / 8; ++c) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ob + (int64_t)r * os + c * 8);
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dob + (int64_t)r * os + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)a[e] * (float)d[e];
+      }
+      L = lse[(int64_t)bh * N + r];
+    }
+    sLse[r] = L;
+    sDel[r] = dl;
+  }
+  __syncthreads();
+  const float scale = rsqrtf((float)DH);
+  const int g = lane >> 4;
+  constexpr int ND = DH / 16;
+  const int ntile = Npad >> 4, npair = Npad >> 5;
+
+  // ---- role 1: own a 16-key tile -> dK, dV -------------------------------------------------------------
+  for (int kt = wave; kt * 16 < N; kt += 8) {
+    const int key0 = kt * 16;
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[ks] = frag_row(Kimg, key0, ks, lane);
+      vf[ks] = frag_row(Vimg, key0, ks, lane);
+    }
+    const bool key_ok = key0 + (lane & 15) < N;
+    f32x4 dKt[ND], dVt[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) dKt[dt] = dVt[dt] = f32x4{0, 0, 0, 0};
+    for (int qp = 0; qp < npair; ++qp) {
+      f32x4 P[2], dS[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int q0 = qp * 32 + hh * 16;
+        f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          s = MFMA(frag_row(Qimg, q0, ks, lane), kf[ks], s);     // S[q = 4g+r][key = lane&15]
+          dp = MFMA(frag_row(Dimg, q0, ks, lane), vf[ks], dp);   // dP[q][key]
+        }
+        const f32x4 L4 = *reinterpret_cast<const f32x4*>(sLse + q0 + 4 * g);
+        const f32x4 D4 = *reinterpret_cast<const f32x4*>(sDel + q0 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = key_ok ? __expf(s[r] * scale - L4[r]) : 0.f;
+          P[hh][r] = p;
+          dS[hh][r] = p * (dp[r] - D4[r]) * scale;
+        }
+      }
+      const bf16x8 pa = pack8(P[0], P[1]);
+      const bf16x8 dsa = pack8(dS[0], dS[1]);
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        dVt[dt] = MFMA(frag_tr(Dimg, qp * 32, qp * 32 + 16, dt * 16, lane), pa, dVt[dt]);   // dV^T[d][key] += dO^T.P
+        dKt[dt] = MFMA(frag_tr(Qimg, qp * 32, qp * 32 + 16, dt * 16, lane), dsa, dKt[dt]);  // dK^T[d][key] += Q^T.dS
+      }
+    }
+    if (key_ok) {
+      bf16* outk = dqkv + ((int64_t)b * N + key0 + (lane & 15)) * rs + H * DH + h * DH + 4 * g;
+      bf16* outv = outk + H * DH;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        Vec4<bf16>::store(outk + dt * 16, dKt[dt]);
+        Vec4<bf16>::store(outv + dt * 16, dVt[dt]);
+      }
+    }
+  }
+
+  // ---- role 2: own a 16-query tile -> dQ -----------------------------------------------------------------
+  for (int qt = wave; qt * 16 < N; qt += 8) {
+    const int q0 = qt * 16;
+    bf16x8 qf[2], dof[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[ks] = frag_row(Qimg, q0, ks, lane);
+      dof[ks] = frag_row(Dimg, q0, ks, lane);
+    }
+    const float Lq = sLse[q0 + (lane & 15)], Dq = sDel[q0 + (lane & 15)];
+    f32x4 dQt[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) dQt[dt] = f32x4{0, 0, 0, 0};
+    for (int kp = 0; kp < npair; ++kp) {
+      f32x4 dS[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int k0 = kp * 32 + hh * 16;
+        f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          s = MFMA(frag_row(Kimg, k0, ks, lane), qf[ks], s);     // S^T[key = 4g+r][q = lane&15]
+          dp = MFMA(frag_row(Vimg, k0, ks, lane), dof[ks], dp);  // dP^T[key][q]
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = (k0 + 4 * g + r < N) ? __expf(s[r] * scale - Lq) : 0.f;
+          dS[hh][r] = p * (dp[r] - Dq) * scale;
+        }
+      }
+      const bf16x8 dsb = pack8(dS[0], dS[1]);
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt)
+        dQt[dt] = MFMA(frag_tr(Kimg, kp * 32, kp * 32 + 16, dt * 16, lane), dsb, dQt[dt]);  // dQ^T[d][q] += K^T.dS^T
+    }
+    const int q = q0 + (lane & 15);
+    if (q < N) {
+      bf16* outq = dqkv + ((int64_t)b * N + q) * rs + h * DH + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) Vec4<bf16>::store(outq + dt * 16, dQt[dt]);
+    }
+  }
+  (void)ntile;
+}
+
+constexpr int kMaxLds = 160 * 1024;
+inline int npad_of(int N) { return (N + 31) / 32 * 32; }
+inline size_t fwd_lds(int N) { return (size_t)2 * npad_of(N) * kRowBytes; }
+inline size_t bwd_lds(int N) { return (size_t)4 * npad_of(N) * kRowBytes + (size_t)2 * npad_of(N) * sizeof(float); }
+
+template <typename F>
+int set_lds(F func, size_t bytes) {
+  if (bytes <= 64 * 1024) return 0;
+  return check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(func), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
+                   "hipFuncSetAttribute(LDS)");
+}
+
+}  // namespace
+
+bool attention_mfma_supported(int N, int H, int dh) {
+  (void)H;
+  return (dh == 48 || dh == 64) && bwd_lds(N) <= (size_t)kMaxLds;
+}
+
+int attention_fwd_mfma(const void* qkv, int B, int N, int H, int dh, void* o, float* lse, hipStream_t s) {
+  const int Npad = npad_of(N);
+  const size_t lds = fwd_lds(N);
+  if (dh == 48) {
+    if (int rc = set_lds(attn_fwd_mfma_kernel<48>, lds)) return rc;
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel<48>, dim3(B * H), dim3(256), lds, s, (const bf16*)qkv, N, H, Npad, (bf16*)o, lse);
+  } else {
+    if (int rc = set_lds(attn_fwd_mfma_kernel<64>, lds)) return rc;
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel<64>, dim3(B * H), dim3(256), lds, s, (const bf16*)qkv, N, H, Npad, (bf16*)o, lse);
+  }
+  return check_hip(hipGetLastError(), "attention_fwd_mfma");
+}
+
+int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const float* lse, int B, int N, int H, int dh,
+                       void* dqkv, hipStream_t s) {
+  const int Npad = npad_of(N);
+  const size_t lds = bwd_lds(N);
+  if (dh == 48) {
+    if (int rc = set_lds(attn_bwd_mfma_kernel<48>, lds)) return rc;
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel<48>, dim3(B * H), dim3(512), lds, s, (const bf16*)qkv, (const bf16*)o,
+                       (const bf16*)d_o, lse, N, H, Npad, (bf16*)dqkv);
+  } else {
+    if (int rc = set_lds(attn_bwd_mfma_kernel<64>, lds)) return rc;
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel<64>, dim3(B * H), dim3(512), lds, s, (const bf16*)qkv, (const bf16*)o,
+                       (const bf16*)d_o, lse, N, H, Npad, (bf16*)dqkv);
+  }
+  return check_hip(hipGetLastError(), "attention_bwd_mfma");
+}
+
 }  // namespace hct

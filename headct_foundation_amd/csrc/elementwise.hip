@@ -242,15 +242,26 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict_
 }
 
 // out_q[d] = sum_blocks partial[blk][q][d]
-__global__ void fold_partials_kernel(const float* __restrict__ partial, int nblk, int nq_stride, int D, float* o0,
-                                     float* o1, float* o2) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+// 256 threads = 32 columns x 8 row groups; fixed summation order => deterministic
+__global__ void __launch_bounds__(256) fold_partials_kernel(const float* __restrict__ partial, int nblk, int nq_stride, int D,
+                                                            float* o0, float* o1, float* o2) {
+  __shared__ float s_red[8][32];
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + c;
   const int q = blockIdx.y;
   float* out = q == 0 ? o0 : (q == 1 ? o1 : o2);
-  if (d >= D || out == nullptr) return;
+  if (out == nullptr) return;
   float acc = 0.f;
-  for (int b = 0; b < nblk; ++b) acc += partial[((size_t)b * nq_stride + q) * D + d];
-  out[d] = acc;
+  if (d < D)
+    for (int b = rg; b < nblk; b += 8) acc += partial[((size_t)b * nq_stride + q) * D + d];
+  s_red[rg][c] = acc;
+  __syncthreads();
+  if (rg == 0 && d < D) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v += s_red[i][c];
+    out[d] = v;
+  }
 }
 
 // =============================================================================================
@@ -596,7 +607,7 @@ int hct_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
     else rc = launch_ln_bwd<float, float>(dy, x, mean, rstd, gamma, dres, rows, D, dx, dx_shadow, partial, dcolsum != nullptr, nblk, s);
   }
   if (rc) return rc;
-  hipLaunchKernelGGL(fold_partials_kernel, dim3((D + 255) / 256, dcolsum ? 3 : 2), dim3(256), 0, s, partial, nblk, 3, D,
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((D + 31) / 32, dcolsum ? 3 : 2), dim3(256), 0, s, partial, nblk, 3, D,
                      dgamma, dbeta, dcolsum);
   HCT_CHECK_LAUNCH("hct_layernorm_bwd");
   return 0;
@@ -632,7 +643,7 @@ int hct_decoder_assemble_bwd(const float* dy, const int32_t* ids_restore, const 
   const int nblk = min(B, kAsmBlocks);
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(decoder_assemble_bwd_reduce_kernel, dim3(nblk), dim3(threads), 0, s, dy, ids_shuffle, B, L, K, D, partial);
-  hipLaunchKernelGGL(fold_partials_kernel, dim3((D + 255) / 256, 2), dim3(256), 0, s, partial, nblk, 2, D, dmask_token,
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((D + 31) / 32, 2), dim3(256), 0, s, partial, nblk, 2, D, dmask_token,
                      ddec_cls, (float*)nullptr);
   HCT_CHECK_LAUNCH("hct_decoder_assemble_bwd");
   return 0;
@@ -688,7 +699,7 @@ int hct_colsum(const void* x, int dtype, int rows, int cols, int64_t ld, float* 
   HCT_DISPATCH_DTYPE(dtype, T,
                      hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3((cols + 255) / 256, chunks), dim3(256), 0, s,
                                         (const T*)x, rows, cols, ld, rpc, partial));
-  hipLaunchKernelGGL(fold_partials_kernel, dim3((cols + 255) / 256, 1), dim3(256), 0, s, partial, chunks, 1, cols, out,
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((cols + 31) / 32, 1), dim3(256), 0, s, partial, chunks, 1, cols, out,
                      (float*)nullptr, (float*)nullptr);
   HCT_CHECK_LAUNCH("hct_colsum");
   return 0;

@@ -12,6 +12,7 @@
 // buffer descriptor's num_records), two LDS buffers, XOR-swizzled so every fragment read is bank-conflict-free,
 // XCD-aware tile order (tiles that share an A row-panel run back-to-back on one XCD's L2).
 #include "common.h"
+#include "prof.h"
 
 namespace hct {
 
@@ -404,7 +405,9 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
   hipStream_t s = (hipStream_t)stream;
   Epilogue e = make_epilogue(a);
   const Path path = choose_path(a);
+  const double flops = 2.0 * a->M * a->N * a->K;
   if (path == PATH_NT) {
+    ProfScope ps(PROF_GEMM_NT, flops, s);
     const int tiles = ((a->M + 127) / 128) * ((a->N + 127) / 128);
     hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(tiles), dim3(256), 0, s, a->M, a->N, a->K, (const bf16*)a->A, a->lda,
                        (const bf16*)a->B, a->ldb, e);
@@ -412,6 +415,7 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
     return 0;
   }
   if (path == PATH_TN) {
+    ProfScope ps(PROF_GEMM_TN, flops, s);
     int splits, r_chunk;
     tn_split(a, splits, r_chunk);
     const int tiles = ((a->M + 127) / 128) * ((a->N + 127) / 128);
@@ -434,6 +438,7 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
     return 0;
   }
   // generic
+  ProfScope ps(PROF_GEMM_GENERIC, flops, s);
   const int64_t sam = a->transA ? 1 : a->lda, sak = a->transA ? a->lda : 1;
   const int64_t sbk = a->transB ? 1 : a->ldb, sbn = a->transB ? a->ldb : 1;
   const int vec_ok = epilogue_vec_ok(a) ? 1 : 0;

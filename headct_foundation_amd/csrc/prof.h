@@ -1,0 +1,13 @@
+#pragma once
+#include <hip/hip_runtime.h>
+namespace hct {
+// kernel classes for hct_prof_read
+enum { PROF_GEMM_NT = 0, PROF_GEMM_TN = 1, PROF_GEMM_GENERIC = 2, PROF_ATTN_FWD = 3, PROF_ATTN_BWD = 4, PROF_LN = 5,
+       PROF_OPTIM = 6 };
+bool prof_enabled();
+struct ProfScope {
+  ProfScope(int id, double work, hipStream_t s);
+  ~ProfScope();
+  int id_; double work_; hipStream_t s_; bool on_; void* a_ = nullptr; void* b_ = nullptr;
+};
+}  // namespace hct

@@ -1,0 +1,83 @@
+"""Data-parallel wrapper: bucketed gradient all-reduce over RCCL, overlapped with the staged backward.
+
+Replaces `torch.nn.parallel.DistributedDataParallel(model, device_ids=[device], broadcast_buffers=False,
+find_unused_parameters=True)` at main_pretrain_mae.py:139 for the HIP model:
+  * construction broadcasts the flat fp32 parameter buffer from rank 0 (DDP ctor semantics);
+  * the native backward runs in stages that each complete one contiguous range of the flat gradient buffer,
+    from its end towards its start (csrc/mae_plan.hip).  After each stage the finished range is appended to
+    the open bucket; once a bucket holds >= bucket_cap_mb it is all-reduced asynchronously
+    (`torch.distributed` backend "nccl" == RCCL; the collective is ordered after the producing kernels on the
+    compute stream and runs on the process group's own stream, so it overlaps the remaining backward);
+  * the mean over ranks costs nothing: the backward is seeded with dLoss/world_size, so the SUM all-reduce
+    already yields the average;
+  * one process per GPU, no data-path collective other than this one (pure data parallelism).
+`state_dict()` keys carry the `module.` prefix exactly like the reference's checkpoints (misc.py:38).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class DistributedDataParallel(nn.Module):
+    def __init__(self, module: nn.Module, device_ids=None, broadcast_buffers: bool = False,
+                 find_unused_parameters: bool = False, bucket_cap_mb: float = 64.0, process_group=None):
+        super().__init__()
+        for attr in ("_flat", "_flat_grad", "_bucket_hook", "_post_backward_hook"):
+            if not hasattr(module, attr):
+                raise TypeError("DistributedDataParallel (HIP) wraps the HIP MaskedAutoencoderViT (flat-buffer model)")
+        self.module = module
+        self.process_group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.bucket_bytes = int(bucket_cap_mb * (1 << 20))
+        self._open: Optional[Tuple[int, int]] = None  # [begin, end) of the bucket being filled
+        self._works: List = []
+        self.launched: List[Tuple[int, int]] = []      # ranges reduced during the last backward (for tests)
+        if self.world_size > 1:
+            dist.broadcast(module._flat, src=0, group=process_group)  # DDP ctor: rank 0's parameters win
+            if hasattr(module, "mark_weights_updated"):
+                module.mark_weights_updated()
+        module._grad_prescale = 1.0 / self.world_size
+        module._bucket_hook = self._on_stage
+        module._post_backward_hook = self._finish
+
+    # called by the model after backward stage `stage` has been enqueued; [begin, end) is now final
+    def _on_stage(self, stage: int, begin: int, end: int) -> None:
+        if self.world_size == 1:
+            return
+        if stage == 0:
+            self.launched = []
+        if self._open is None:
+            self._open = (begin, end)
+        else:
+            ob, oe = self._open
+            if end != ob:  # not adjacent (should not happen): flush and restart
+                self._launch(ob, oe)
+                self._open = (begin, end)
+            else:
+                self._open = (begin, oe)
+        ob, oe = self._open
+        if (oe - ob) * 4 >= self.bucket_bytes:
+            self._launch(ob, oe)
+            self._open = None
+
+    def _launch(self, begin: int, end: int) -> None:
+        view = self.module._flat_grad[begin:end]
+        self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
+        self.launched.append((begin, end))
+
+    def _finish(self) -> None:
+        if self.world_size == 1:
+            return
+        if self._open is not None:
+            self._launch(*self._open)
+            self._open = None
+        for w in self._works:
+            w.wait()  # compute stream waits for the collective (no host block on NCCL/RCCL)
+        self._works = []
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)

@@ -223,6 +223,7 @@ class MaskedAutoencoderViT(nn.Module):
         self._bucket_hook: Optional[Callable[[int, int, int], None]] = None  # (stage, begin, end) after each stage
         self._post_backward_hook: Optional[Callable[[], None]] = None
         self._grad_overwrite = True    # next backward overwrites the flat gradient (set by zero_grad paths)
+        self._grad_prescale = 1.0
         self._managed_updates = False  # True once a HipAdamW owns the weight updates
         self._plain_fresh = False
         self._layout: List[Tuple[str, int, int, Tuple[int, ...], bool, int]] = []
@@ -390,6 +391,8 @@ class MaskedAutoencoderViT(nn.Module):
         if accumulate:
             prev = self._flat_grad.clone()
         g = grad_out.detach().to(dtype=torch.float32).reshape(1).contiguous()
+        if self._grad_prescale != 1.0:  # data-parallel mean folded into the backward seed (ddp.py)
+            g = g * self._grad_prescale
         _lib.check(lib.hct_mae_set_loss_grad(plan.handle, g.data_ptr()), "hct_mae_set_loss_grad")
         for s in range(plan.nstages):
             _lib.check(lib.hct_mae_backward_stage(plan.handle, s, x.data_ptr(), st), f"hct_mae_backward_stage({s})")

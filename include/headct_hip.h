@@ -237,6 +237,18 @@ int hct_mae_backward_stage(hct_mae_plan*, int stage, const float* x, void* strea
 /* named activation lookup for parity tests: returns device pointer + shape/dtype, or NULL. */
 const void* hct_mae_plan_activation(const hct_mae_plan*, const char* name, int64_t* rows, int64_t* cols, int* dtype);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py roofline leg): when enabled, every launch of a kernel class is bracketed
+ * by HIP events on its own stream.  id: 0 GEMM-NT (MFMA), 1 GEMM-TN (MFMA), 2 GEMM-generic,
+ * 3 attention fwd, 4 attention bwd.  hct_prof_read blocks until the recorded launches finished and returns
+ * their summed duration, launch count and summed algorithmic work (FLOPs).
+ * ------------------------------------------------------------------------------------------ */
+void hct_prof_enable(int on);
+void hct_prof_reset(void);
+int hct_prof_read(int id, double* total_ms, int64_t* launches, double* work);
+/* testing hook: route bf16 attention through the fp32-math kernels */
+void hct_debug_force_simple_attention(int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,244 @@
+"""Per-kernel parity through the C ABI (include/headct_hip.h) against plain PyTorch fp32 references of the same op.
+Shapes are the MAE tile shapes (N = 55 / 217 tokens, head dim 64 / 48, D = 768 ...) plus ragged / edge cases."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from headct_foundation_amd import _lib
+from headct_foundation_amd._lib import HCT_BF16, HCT_F32, GemmArgs
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t):
+    return HCT_BF16 if t.dtype == torch.bfloat16 else HCT_F32
+
+
+def gemm(lib, A, B, transA, transB, M, N, K, out_dtype=torch.float32, bias=None, residual=None, act=0, aux=None,
+         force_generic=False, c2_dtype=None):
+    dev = A.device
+    Cm = torch.empty(M, N, dtype=out_dtype, device=dev)
+    C2 = torch.empty(M, N, dtype=c2_dtype, device=dev) if c2_dtype is not None else None
+    a = GemmArgs()
+    a.M, a.N, a.K = M, N, K
+    a.A, a.a_dtype, a.lda, a.transA = A.data_ptr(), _dt(A), A.stride(0), int(transA)
+    a.B, a.b_dtype, a.ldb, a.transB = B.data_ptr(), _dt(B), B.stride(0), int(transB)
+    a.C, a.c_dtype, a.ldc = Cm.data_ptr(), _dt(Cm), N
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.residual = residual.data_ptr() if residual is not None else None
+    a.ldr = N
+    a.act = act
+    if aux is not None:
+        a.aux, a.aux_dtype, a.ldaux = aux.data_ptr(), _dt(aux), N
+    if C2 is not None:
+        a.C2, a.c2_dtype, a.ldc2 = C2.data_ptr(), _dt(C2), N
+    a.alpha = 1.0
+    a.force_generic = int(force_generic)
+    ws_bytes = lib.hct_gemm_workspace_bytes(C.byref(a))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    _lib.check(lib.hct_gemm(C.byref(a), ws.data_ptr(), ws.numel(), _st()), "hct_gemm")
+    return (Cm, C2) if C2 is not None else Cm
+
+
+def _rand(shape, dev, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(device=dev, dtype=dtype)
+
+
+@pytest.mark.parametrize("M,N,K", [(55 * 3, 768, 768), (217 * 2, 2304, 768), (130, 3072, 768), (128, 768, 3072),
+                                   (100, 192, 192), (1, 64, 64), (257, 4096, 768), (300, 48, 64)])
+def test_gemm_nt_bf16_mfma(lib, cuda, M, N, K):
+    A = _rand((M, K), cuda, torch.bfloat16, 1)
+    B = _rand((N, K), cuda, torch.bfloat16, 2, 0.05)
+    bias = _rand((N,), cuda, torch.float32, 3)
+    res = _rand((M, N), cuda, torch.float32, 4)
+    ref = A.float() @ B.float().t() + bias + res
+    out = gemm(lib, A, B, 0, 1, M, N, K, bias=bias, residual=res)
+    gen = gemm(lib, A, B, 0, 1, M, N, K, bias=bias, residual=res, force_generic=True)
+    assert rel_err(out, ref) < 1e-5 and rel_err(gen, ref) < 1e-5  # exact bf16 products, fp32 accumulate
+    # GELU epilogue with pre-activation side output, bf16 stores
+    aux = torch.empty(M, N, dtype=torch.bfloat16, device=cuda)
+    o2 = gemm(lib, A, B, 0, 1, M, N, K, out_dtype=torch.bfloat16, bias=bias, act=1, aux=aux)
+    pre = A.float() @ B.float().t() + bias
+    assert rel_err(aux, pre) < 4e-3 and rel_err(o2, F.gelu(pre)) < 4e-3
+    # dGELU epilogue
+    dy = gemm(lib, A, B, 0, 1, M, N, K, out_dtype=torch.bfloat16, act=2, aux=aux)
+    u = aux.float().requires_grad_(True)
+    F.gelu(u).sum().backward()
+    assert rel_err(dy, (A.float() @ B.float().t()) * u.grad) < 4e-3
+
+
+@pytest.mark.parametrize("R,M,N", [(217 * 4, 768, 768), (55 * 5, 2304, 768), (1000, 768, 3072), (64, 192, 192),
+                                   (5000, 4096, 768), (33, 48, 64), (130, 576, 192)])
+def test_gemm_tn_bf16_mfma(lib, cuda, R, M, N):
+    """wgrad: C[M,N] = A[R,M]^T . B[R,N]; ragged reduction lengths exercise the zero-fill path and split-K."""
+    A = _rand((R, M), cuda, torch.bfloat16, 5)
+    B = _rand((R, N), cuda, torch.bfloat16, 6)
+    ref = A.float().t() @ B.float()
+    out = gemm(lib, A, B, 1, 0, M, N, R)
+    gen = gemm(lib, A, B, 1, 0, M, N, R, force_generic=True)
+    assert rel_err(out, ref) < 2e-5 and rel_err(gen, ref) < 2e-5
+    out2 = gemm(lib, A, B, 1, 0, M, N, R)
+    assert torch.equal(out, out2)  # deterministic split-K fold
+
+
+def test_gemm_generic_fp32_all_layouts(lib, cuda):
+    M, N, K = 77, 53, 45
+    A, B = _rand((M, K), cuda, torch.float32, 7), _rand((K, N), cuda, torch.float32, 8)
+    ref = A @ B
+    assert rel_err(gemm(lib, A, B.contiguous(), 0, 0, M, N, K), ref) < 1e-5
+    assert rel_err(gemm(lib, A, B.t().contiguous(), 0, 1, M, N, K), ref) < 1e-5
+    assert rel_err(gemm(lib, A.t().contiguous(), B.contiguous(), 1, 0, M, N, K), ref) < 1e-5
+    assert rel_err(gemm(lib, A.t().contiguous(), B.t().contiguous(), 1, 1, M, N, K), ref) < 1e-5
+    assert gemm(lib, A[:0], B.contiguous(), 0, 0, 0, N, K).numel() == 0  # empty
+
+
+def _attn_ref(qkv, B, N, H, dh):
+    q, k, v = qkv.float().view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, N, H * dh)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,N,H,dh,dtype", [(2, 55, 12, 64, torch.bfloat16), (2, 217, 16, 48, torch.bfloat16),
+                                            (3, 17, 3, 64, torch.bfloat16), (1, 1, 2, 48, torch.bfloat16),
+                                            (2, 65, 3, 64, torch.float32), (2, 217, 4, 48, torch.float32),
+                                            (2, 33, 3, 16, torch.float32), (1, 129, 2, 64, torch.bfloat16),
+                                            (1, 513, 2, 48, torch.bfloat16)])
+def test_attention_fwd_bwd(lib, cuda, B, N, H, dh, dtype):
+    qkv = _rand((B, N, 3 * H * dh), cuda, dtype, 11)
+    d_o = _rand((B, N, H * dh), cuda, dtype, 12)
+    qr = qkv.float().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(qr, B, N, H, dh)
+    (o_ref * d_o.float()).sum().backward()
+    dt = _dt(qkv)
+    tol = 1.5e-2 if dtype == torch.bfloat16 else 2e-5
+    for force_simple in ((0, 1) if dtype == torch.bfloat16 else (0,)):
+        lib.hct_debug_force_simple_attention(force_simple)
+        try:
+            o = torch.empty(B, N, H * dh, dtype=dtype, device=cuda)
+            lse = torch.empty(B, H, N, dtype=torch.float32, device=cuda)
+            _lib.check(lib.hct_attention_fwd(qkv.data_ptr(), B, N, H, dh, dt, o.data_ptr(), lse.data_ptr(), _st()), "fwd")
+            dqkv = torch.full_like(qkv, float("nan"))
+            _lib.check(lib.hct_attention_bwd(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), B, N, H, dh, dt,
+                                             dqkv.data_ptr(), _st()), "bwd")
+            torch.cuda.synchronize()
+        finally:
+            lib.hct_debug_force_simple_attention(0)
+        assert rel_err(o, o_ref) < tol, force_simple
+        assert (lse - lse_ref).abs().max() < (2e-2 if dtype == torch.bfloat16 else 1e-4)
+        assert torch.isfinite(dqkv.float()).all()
+        assert rel_err(dqkv, qr.grad) < 2 * tol, force_simple
+
+
+@pytest.mark.parametrize("rows,D,dtype", [(55 * 2, 768, torch.bfloat16), (217, 768, torch.float32), (7, 48, torch.float32),
+                                          (1030, 1024, torch.bfloat16), (5, 192, torch.bfloat16)])
+def test_layernorm_fwd_bwd(lib, cuda, rows, D, dtype):
+    x = _rand((rows, D), cuda, torch.float32, 21) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * _rand((D,), cuda, torch.float32, 22), 0.1 * _rand((D,), cuda, torch.float32, 23)
+    dy = _rand((rows, D), cuda, dtype, 24)
+    dres = _rand((rows, D), cuda, torch.float32, 25)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = F.layer_norm(xr, (D,), gr, br, 1e-5)
+    (y_ref * dy.float()).sum().backward()
+    y = torch.empty(rows, D, dtype=dtype, device=cuda)
+    mean, rstd = torch.empty(rows, device=cuda), torch.empty(rows, device=cuda)
+    _lib.check(lib.hct_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, D, 1e-5, y.data_ptr(), _dt(y),
+                                     mean.data_ptr(), rstd.data_ptr(), _st()), "ln fwd")
+    assert rel_err(y, y_ref) < (4e-3 if dtype == torch.bfloat16 else 1e-5)
+    ws = torch.empty(lib.hct_layernorm_bwd_workspace_bytes(rows, D), dtype=torch.uint8, device=cuda)
+    dx = dres.clone()
+    shadow = torch.empty(rows, D, dtype=dtype, device=cuda)
+    dg, db, dc = (torch.empty(D, device=cuda) for _ in range(3))
+    _lib.check(lib.hct_layernorm_bwd(dy.data_ptr(), _dt(dy), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                     dx.data_ptr(), rows, D, dx.data_ptr(), shadow.data_ptr(), _dt(shadow), dg.data_ptr(),
+                                     db.data_ptr(), dc.data_ptr(), ws.data_ptr(), ws.numel(), _st()), "ln bwd")
+    want = xr.grad + dres
+    assert rel_err(dx, want) < 1e-5
+    assert rel_err(shadow, want) < (4e-3 if dtype == torch.bfloat16 else 1e-5)
+    assert rel_err(dg, gr.grad) < 1e-5 and rel_err(db, br.grad) < 1e-5
+    assert rel_err(dc, want.sum(0)) < 1e-4
+
+
+def test_mask_rank_with_ties(lib, cuda):
+    B, L, K = 5, 216, 54
+    noise = torch.rand(B, L)
+    noise[0, 10] = noise[0, 3]
+    noise[1, :] = 0.5  # all ties: stable order = identity
+    nz = noise.to(cuda)
+    idr, ids = torch.empty(B, L, dtype=torch.int32, device=cuda), torch.empty(B, L, dtype=torch.int32, device=cuda)
+    mask = torch.empty(B, L, device=cuda)
+    _lib.check(lib.hct_mask_rank(nz.data_ptr(), B, L, K, idr.data_ptr(), ids.data_ptr(), mask.data_ptr(), _st()), "rank")
+    shuffle = torch.argsort(noise, dim=1, stable=True)
+    restore = torch.argsort(shuffle, dim=1, stable=True)
+    assert torch.equal(ids.cpu().long(), shuffle) and torch.equal(idr.cpu().long(), restore)
+    assert torch.equal(mask.cpu(), (restore >= K).float())
+    assert torch.equal(ids[1].cpu().long(), torch.arange(L))
+
+
+def test_colsum_cast_transpose(lib, cuda):
+    for rows, cols, dtype in ((1000, 768, torch.bfloat16), (37, 2304, torch.float32), (1, 4, torch.float32)):
+        x = _rand((rows, cols), cuda, dtype, 31)
+        ws = torch.empty(max(16, lib.hct_colsum_workspace_bytes(rows, cols)), dtype=torch.uint8, device=cuda)
+        out = torch.empty(cols, device=cuda)
+        _lib.check(lib.hct_colsum(x.data_ptr(), _dt(x), rows, cols, cols, out.data_ptr(), ws.data_ptr(), ws.numel(), _st()), "colsum")
+        assert rel_err(out, x.float().sum(0)) < 1e-5
+    w = _rand((300, 130), cuda, torch.float32, 32)
+    wt = torch.empty(130, 300, dtype=torch.bfloat16, device=cuda)
+    _lib.check(lib.hct_transpose_cast(w.data_ptr(), HCT_F32, wt.data_ptr(), HCT_BF16, 300, 130, _st()), "tcast")
+    assert torch.equal(wt, w.t().to(torch.bfloat16))
+    flat = _rand((100003,), cuda, torch.float32, 33)
+    fb = torch.empty(100003, dtype=torch.bfloat16, device=cuda)
+    _lib.check(lib.hct_cast(flat.data_ptr(), HCT_F32, fb.data_ptr(), HCT_BF16, flat.numel(), _st()), "cast")
+    assert torch.equal(fb, flat.to(torch.bfloat16))
+
+
+def test_clip_and_adamw_vs_torch(lib, cuda):
+    """hct_grad_norms + hct_adamw_step against torch.optim.AdamW + the reference's per-tensor clip."""
+    sizes = [1024, 3072, 2048, 1024]
+    seg = [0]
+    for s in sizes:
+        seg.append(seg[-1] + s)
+    total = seg[-1]
+    p0 = _rand((total,), cuda, torch.float32, 41)
+    g0 = _rand((total,), cuda, torch.float32, 42)
+    g0[seg[1]:seg[2]] *= 100.0  # this tensor gets clipped
+    g0[seg[2]:seg[3]] *= 1e-3   # this one does not
+    clip = 3.0
+    params = [torch.nn.Parameter(p0[seg[i]:seg[i + 1]].clone()) for i in range(4)]
+    opt = torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.95), weight_decay=5e-3)
+    p, g = p0.clone(), g0.clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    seg_t = torch.tensor(seg, dtype=torch.int64, device=cuda)
+    skip = torch.tensor([0, 0, 0, 1], dtype=torch.uint8, device=cuda)
+    norms, coef = torch.empty(4, device=cuda), torch.empty(4, device=cuda)
+    ws = torch.empty(lib.hct_grad_norms_workspace_bytes(total), dtype=torch.uint8, device=cuda)
+    shadow = torch.empty(total, dtype=torch.bfloat16, device=cuda)
+    for step in range(1, 4):
+        gstep = g0 * (1.0 + 0.1 * step)
+        g.copy_(gstep)
+        for i, prm in enumerate(params):
+            prm.grad = gstep[seg[i]:seg[i + 1]].clone()
+            n = prm.grad.norm(2)
+            c = clip / (n + 1e-6)
+            if c < 1:
+                prm.grad.mul_(c)
+        params[3].grad = None  # frozen segment
+        opt.step()
+        _lib.check(lib.hct_grad_norms(g.data_ptr(), seg_t.data_ptr(), 4, total, clip, 0, norms.data_ptr(), coef.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), _st()), "norms")
+        _lib.check(lib.hct_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), seg_t.data_ptr(), coef.data_ptr(),
+                                      skip.data_ptr(), 4, total, 1e-3, 0.9, 0.95, 1e-8, 5e-3, step, shadow.data_ptr(), _st()), "adamw")
+        for i in range(3):
+            assert rel_err(p[seg[i]:seg[i + 1]], params[i].data) < 1e-6, (step, i)
+            assert rel_err(g[seg[i]:seg[i + 1]], params[i].grad) < 1e-6  # clipped gradient written back
+        assert torch.equal(p[seg[3]:], p0[seg[3]:])  # skipped segment untouched
+    assert float(coef[1]) < 1.0 and float(coef[2]) == 1.0
+    assert torch.equal(shadow[:seg[3]], p[:seg[3]].to(torch.bfloat16))
