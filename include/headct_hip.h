@@ -248,6 +248,8 @@ void hct_prof_reset(void);
 int hct_prof_read(int id, double* total_ms, int64_t* launches, double* work);
 /* testing hook: route bf16 attention through the fp32-math kernels */
 void hct_debug_force_simple_attention(int on);
+/* testing hook: force the NT GEMM tile variant (0 auto, 128, 256) */
+void hct_debug_set_gemm_variant(int v);
 
 #ifdef __cplusplus
 }
