@@ -1,0 +1,91 @@
+"""CPU: the oracle (oracle/mae_oracle.py) against the golden fixtures generated from the REFERENCE itself
+(tests/golden/make_golden.py imports the reference's own modules with stand-ins for MONAI/timm symbols)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mae_oracle as O
+from tests.util import GOLDEN, load_golden, sample_of
+
+CASES = [("micro", 2, 0), ("yaml_cut", 2, 1), ("tiny", 2, 0), ("vitb_cut", 2, 0)]
+
+
+@pytest.mark.parametrize("name,batch,seed", CASES)
+def test_oracle_forward_backward_matches_reference_outputs(name, batch, seed):
+    fx = load_golden(f"{name}_b{batch}_s{seed}")
+    cfg = O.CONFIGS[name]
+    params = O.make_params(cfg, seed)
+    x, noise = O.make_volume(cfg, batch, seed), O.make_noise(cfg, batch, seed)
+    loss, pred, mask, grads, inter = O.forward_backward(cfg, params, x, noise, want_inter=True)
+    assert abs(float(loss) - fx["loss"]) <= 2e-6 * abs(fx["loss"])
+    assert float(mask.sum()) == fx["mask_sum"]
+    for key, entry in fx["act"].items():
+        got, want, l2, l2w = sample_of(inter[key], entry)
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), key
+        assert abs(l2 - l2w) <= 1e-5 * l2w
+    got, want, l2, l2w = sample_of(pred, fx["pred"])
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5)
+    got, want, _, _ = sample_of(O.unpatchify(cfg, pred), fx["unpatchify_pred"])
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5)
+    got, want, _, _ = sample_of(O.patchify(cfg, x), fx["patchify_x"])
+    assert torch.equal(got, want)
+    assert set(grads) == set(fx["grads"])
+    for k, entry in fx["grads"].items():
+        got, want, l2, l2w = sample_of(grads[k], entry)
+        if k.endswith("qkv.bias"):  # K-third: mathematically zero gradient, round-off only
+            assert (got - want).abs().max() < 1e-7 + 1e-4 * float(want.abs().max())
+        else:
+            assert torch.allclose(got, want, rtol=2e-4, atol=1e-5 * float(want.abs().max()) + 1e-12), k
+
+
+@pytest.mark.parametrize("name,batch,seed", [("micro", 2, 0), ("tiny", 2, 0)])
+def test_oracle_train_curve_matches_reference_engine(name, batch, seed):
+    """loss curve / LR values / parameters after N steps of the reference's own train_one_epoch."""
+    fx = load_golden(f"{name}_b{batch}_s{seed}")
+    hp, steps = fx["train"]["hp"], fx["train"]["steps"]
+    cfg = O.CONFIGS[name]
+    st = O.TrainState(O.make_params(cfg, seed))
+    losses, lrs = [], []
+    for i in range(steps):
+        l, lr, _, _ = O.train_step(cfg, st, O.make_volume(cfg, batch, seed + 10 + i), O.make_noise(cfg, batch, seed + 10 + i), **hp)
+        losses.append(l); lrs.append(lr)
+    assert np.allclose(lrs, fx["train"]["lrs"], rtol=1e-12)
+    assert np.allclose(losses, fx["train"]["logged_losses"], atol=6e-5)
+    for k, entry in fx["train"]["params_after"].items():
+        got, want, _, _ = sample_of(st.params[k], entry)
+        atol = 4 * hp["base_lr"] if k.endswith("qkv.bias") else 1e-6
+        assert torch.allclose(got, want, rtol=1e-5, atol=atol), k
+
+
+def test_oracle_full_tensors_micro():
+    z = np.load(os.path.join(GOLDEN, "micro_b2_s0_full.npz"))
+    cfg = O.CONFIGS["micro"]
+    loss, pred, _, grads, inter = O.forward_backward(cfg, O.make_params(cfg, 0), O.make_volume(cfg, 2, 0), O.make_noise(cfg, 2, 0), True)
+    assert abs(float(loss) - float(z["loss"])) < 1e-6
+    assert np.allclose(pred.numpy(), z["pred"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(inter["latent"].numpy(), z["latent"], rtol=1e-4, atol=1e-5)
+    for k, g in grads.items():
+        if not k.endswith("qkv.bias"):
+            assert np.allclose(g.numpy(), z["grad." + k], rtol=1e-3, atol=1e-6 * np.abs(z["grad." + k]).max() + 1e-9), k
+
+
+def test_lr_schedule_and_sincos_golden():
+    with open(os.path.join(GOLDEN, "lr_schedule.json")) as f:
+        fx = json.load(f)
+    got = [fx["base_lr"] * O.cosine_warmup_lambda(s, fx["warmup"], fx["total"], fx["base_lr"], fx["min_lr"]) for s in range(len(fx["lrs"]))]
+    assert np.allclose(got, fx["lrs"], rtol=1e-12)
+    with open(os.path.join(GOLDEN, "sincos.json")) as f:
+        sc = json.load(f)
+    for key, entry in sc.items():
+        g, d = map(int, key.split("_"))
+        got, want, _, _ = sample_of(O.build_sincos_position_embedding_3d(g, d), entry)
+        assert torch.equal(got, want)
+
+
+def test_algorithmic_flops_match_survey():
+    f = O.algorithmic_flops_per_volume(O.CONFIGS["vitb"])
+    assert abs(f["train"] / 1e9 - 110.85) < 0.01  # SURVEY 8d / BASELINE.md
+    assert abs(O.algorithmic_flops_per_volume(O.CONFIGS["tiny"])["train"] / 1e9 - 1.295) < 0.001
