@@ -48,10 +48,20 @@ def algorithmic_train_flops_per_volume(c) -> float:
     return 3.0 * fwd
 
 
+def _host_threads() -> int:
+    """Threads to use for the CPU baseline: the CPUs this process may run on, capped at the GPU box's 16-CPU share."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(seconds_budget: float = 25.0):
-    """Oracle train step on the host cores: ViT-B, B=8 (SURVEY 8d / BASELINE.md 3).  Bounded sample."""
+    """Oracle train step on the host cores: ViT-B, B=8 (SURVEY 8d / BASELINE.md 3).  Bounded sample (~seconds_budget)."""
     from oracle import mae_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads = _host_threads()
+    torch.set_num_threads(threads)
     cfg = O.CONFIGS["vitb"]
     B = 8
     st = O.TrainState(O.make_params(cfg, 42, generic=False))
@@ -62,16 +72,15 @@ def cpu_baseline(seconds_budget: float = 25.0):
     for i in range(8):
         t0 = time.time()
         O.train_step(cfg, st, x, noise, **hp)
-        dt = time.time() - t0
-        if i >= 1:
-            times.append(dt)
-        if time.time() - t_start > seconds_budget and len(times) >= 2:
+        times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget:
             break
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": round(B / med, 3), "unit": "CT-volumes/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/mae_oracle.py train_step, ViT-B/16^3 96^3x1ch fp32, B={B}, median of {len(times)} steps after 1 warm-up "
-                      f"({med:.2f} s/step); host has {os.cpu_count()} logical cores"}
+    timed = sorted(times[1:]) if len(times) > 1 else times  # first step = warm-up unless it is all the budget allowed
+    med = timed[len(timed) // 2]
+    return {"value": round(B / med, 3), "unit": "CT-volumes/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/mae_oracle.py train_step, ViT-B/16^3 96^3x1ch fp32, B={B}, median of {len(timed)} step(s)"
+                      f"{' after 1 warm-up' if len(times) > 1 else ' (no warm-up fitted the budget)'} ({med:.2f} s/step); "
+                      f"{threads} torch threads, host reports {os.cpu_count()} logical CPUs"}
 
 
 def main():

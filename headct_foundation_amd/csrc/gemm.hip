@@ -398,7 +398,7 @@ __device__ __forceinline__ void epilogue_tile16x128(const Epilogue& e, unsigned 
 //   EPI_GELU_BF16  : aux(bf16) = alpha*acc + bias ; C(bf16) = gelu(aux)  linear1 forward
 //   EPI_DGELU_BF16 : C(bf16) = alpha*acc * gelu'(aux(bf16))             linear2 dgrad
 //   EPI_GENERIC    : everything else (runtime flags)
-enum { EPI_GENERIC = 0, EPI_PLAIN_BF16 = 1, EPI_RES_F32 = 2, EPI_GELU_BF16 = 3, EPI_DGELU_BF16 = 4 };
+enum { EPI_GENERIC = 0, EPI_PLAIN_BF16 = 1, EPI_RES_F32 = 2, EPI_GELU_BF16 = 3, EPI_DGELU_BF16 = 4, EPI_PLAIN_F32 = 5 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -478,8 +478,8 @@ __device__ __forceinline__ void epilogue_tile16x128_m(const Epilogue& e, const T
       if (MODE == EPI_PLAIN_BF16) {
         bf16x4 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), tb.c, vc2, sc2, 0);
-      } else if (MODE == EPI_RES_F32) {
-        x += r[it];
+      } else if (MODE == EPI_RES_F32 || MODE == EPI_PLAIN_F32) {
+        if (MODE == EPI_RES_F32) x += r[it];
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), tb.c, vc4, sc4, 0);
       } else if (MODE == EPI_GELU_BF16) {
         bf16x4 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
@@ -687,6 +687,184 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
   }
 }
 
+// ---- TN, 256x256 tile: C[M,N] (+)= A[R,M]^T . B[R,N]  (wgrad), same ring / pipeline / epilogue as the NT kernel ------
+// LDS stage = A[32 r][256 m] | B[32 r][256 n] bf16 (512-B rows = whole lines per DMA piece of 2 rows); the 32-B block nb of
+// row r sits at block  nb ^ f(r),  f(r) = (r&3) | ((r>>3)&1)<<2, which makes the ds_read_b64_tr_b16 fragment reads
+// conflict-free.  Work item = (split over R, tile); every split reduces r_chunk rows (zero-filled past R) and writes an
+// fp32 partial (or the final C when splits == 1); a fold kernel adds the partials in fixed order.
+__global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, int R, int r_chunk, const bf16* __restrict__ A,
+                                                                 int64_t lda, const bf16* __restrict__ B, int64_t ldb,
+                                                                 float* __restrict__ slab, Epilogue e, int ntiles) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[163840];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ntm = (M + 255) >> 8, ntn = (N + 255) >> 8, nmn = ntm * ntn;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = r_chunk >> 5;
+  const uint32_t OOB = 0xFFFFFFF0u;
+
+  // staging: 1 KiB piece = 2 reduction rows x 512 B; wave w moves pieces 2w, 2w+1 of A and of B each stage
+  int srow[2], scol[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    srow[i] = (wave * 2 + i) * 2 + (lane >> 5);
+    const int slot = lane & 31;
+    const int f = (srow[i] & 3) | (((srow[i] >> 3) & 1) << 2);
+    scol[i] = ((((slot >> 1) ^ f) << 1) | (slot & 1)) * 8;
+  }
+  uint32_t voa[2], vob[2];
+  __amdgpu_buffer_rsrc_t ra, rb;
+  int m0 = 0, n0 = 0, sp = 0;
+  auto set_tile = [&](int vb) {
+    const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    sp = id / nmn;
+    const int rem = id - sp * nmn;
+    const int tm = rem / ntn, tn = rem - tm * ntn;
+    m0 = tm << 8;
+    n0 = tn << 8;
+    const int rbeg = sp * r_chunk;
+    const int rows = min(R, rbeg + r_chunk) - rbeg;
+    const bf16* Ab = A + (int64_t)rbeg * lda + m0;
+    const bf16* Bb = B + (int64_t)rbeg * ldb + n0;
+    ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, clamp_records(((int64_t)(rows - 1) * lda + (M - m0)) * 2), 0x00020000);
+    rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, clamp_records(((int64_t)(rows - 1) * ldb + (N - n0)) * 2), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      voa[i] = (m0 + scol[i] < M) ? (uint32_t)((srow[i] * lda + scol[i]) * 2) : OOB;
+      vob[i] = (n0 + scol[i] < N) ? (uint32_t)((srow[i] * ldb + scol[i]) * 2) : OOB;
+    }
+  };
+  auto stage = [&](int t) {
+    unsigned char* base = smem + (t & 3) * 32768;
+    const uint32_t ka = (uint32_t)(t * 32 * lda * 2), kb = (uint32_t)(t * 32 * ldb * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = wave * 2 + i;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + c * 1024), 16, voa[i] == OOB ? OOB : voa[i] + ka, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + 16384 + c * 1024), 16, vob[i] == OOB ? OOB : vob[i] + kb, 0, 0, 0);
+    }
+  };
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  const int ff = qq | ((g & 1) << 2);
+  const int rowb = (8 * g + qq) * 512 + pp * 8;
+  auto frag = [&](const unsigned char* tile, int nb) -> bf16x8 {
+    const unsigned char* pa = tile + rowb + ((nb ^ ff) << 5);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * 512));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  f32x4 acc[4][8];
+  bf16x8 b_lo[4], b_hi[4], a0[4], a1[4];
+  auto rd_a = [&](int t, bf16x8* af) {
+    const unsigned char* sa = smem + (t & 3) * 32768;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = frag(sa, wm * 4 + i);
+  };
+  auto rd_b = [&](int t, int half, bf16x8* bq) {
+    const unsigned char* sb = smem + (t & 3) * 32768 + 16384;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bq[j] = frag(sb, wn * 8 + half * 4 + j);
+  };
+  auto mma = [&](int half, const bf16x8* af, const bf16x8* bq) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][half * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[i][half * 4 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto land = [&](int later) {
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  int vb = blockIdx.x;
+  set_tile(vb);
+  stage(0);
+  stage(1);
+  stage(2);
+  while (true) {
+    const int cm0 = m0, cn0 = n0, csp = sp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    land(2);
+    rd_a(0, a0);
+    rd_b(0, 0, b_lo);
+    int t = 0;
+    for (; t + 4 < nk; t += 2) {
+      rd_b(t, 1, b_hi);
+      mma(0, a0, b_lo);
+      land(1);
+      stage(t + 3);
+      rd_a(t + 1, a1);
+      rd_b(t + 1, 0, b_lo);
+      mma(1, a0, b_hi);
+      rd_b(t + 1, 1, b_hi);
+      mma(0, a1, b_lo);
+      land(1);
+      stage(t + 4);
+      rd_a(t + 2, a0);
+      rd_b(t + 2, 0, b_lo);
+      mma(1, a1, b_hi);
+    }
+    rd_b(t, 1, b_hi);
+    mma(0, a0, b_lo);
+    land(1);
+    stage(t + 3);
+    rd_a(t + 1, a1);
+    rd_b(t + 1, 0, b_lo);
+    mma(1, a0, b_hi);
+    rd_b(t + 1, 1, b_hi);
+    mma(0, a1, b_lo);
+    land(1);
+    rd_a(t + 2, a0);
+    rd_b(t + 2, 0, b_lo);
+    mma(1, a1, b_hi);
+    rd_b(t + 2, 1, b_hi);
+    mma(0, a0, b_lo);
+    land(0);
+    rd_a(t + 3, a1);
+    rd_b(t + 3, 0, b_lo);
+    mma(1, a0, b_hi);
+    rd_b(t + 3, 1, b_hi);
+    mma(0, a1, b_lo);
+    mma(1, a1, b_hi);
+
+    __builtin_amdgcn_s_barrier();
+    vb += gridDim.x;
+    const bool more = vb < ntiles;
+    if (more) {
+      set_tile(vb);
+      stage(0);
+      stage(1);
+      stage(2);
+    }
+    {
+      unsigned char* patch = smem + 3 * 32768 + wave * 8192;
+      Epilogue eo = e;
+      if (slab) {  // raw fp32 partial of this split; the fold kernel applies alpha and the output dtype
+        eo.bias = nullptr; eo.alpha = 1.0f;
+        eo.C = slab + (int64_t)csp * M * N; eo.ldc = N;
+      }
+      TileBufs tb;
+      tb.c = tile_rsrc(eo.C, eo.ldc, 4, cm0, cn0, M, N);
+      tb.res = tile_rsrc(nullptr, 0, 4, cm0, cn0, M, N);
+      tb.aux = tb.res;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        epilogue_tile16x128_m<EPI_PLAIN_F32>(eo, tb, patch, lane, cm0, cn0, wm * 64 + i * 16, wn * 128, M, N, acc[i]);
+    }
+    if (!more) break;
+  }
+}
+
 // ---- TN: A stored [R,M] (lda), B stored [R,N] (ldb); C[M,N] = sum_r A[r,m] B[r,n] ------------------------------
 // grid.x = tiles, grid.y = splits over R.  splits > 1: fp32 partials to slab[split][M][N].
 __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_kernel(int M, int N, int R, int r_chunk, const bf16* __restrict__ A,
@@ -843,6 +1021,22 @@ static Path choose_path(const hct_gemm_args* a) {
   return PATH_GENERIC;
 }
 
+static bool tn256_ok(const hct_gemm_args* a) {
+  return g_nt_variant != 128 && a->c_dtype == HCT_F32 && !a->C2 && a->ldc % 4 == 0 && a->ldc * 256 < (1ll << 28) &&
+         a->lda * 2 * 64 < (1ll << 31) && a->ldb * 2 * 64 < (1ll << 31);
+}
+
+static void tn256_split(const hct_gemm_args* a, int& splits, int& r_chunk) {
+  const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+  int s = std::max(1, num_cus() / tiles);
+  int per = (a->K + s - 1) / s;
+  per = std::max(128, (per + 63) / 64 * 64);  // even stage count >= 4
+  // keep a split's operand span inside the 32-bit buffer offset range
+  while ((int64_t)per * std::max(a->lda, a->ldb) * 2 >= (1ll << 31)) per = std::max(128, per / 2 / 64 * 64);
+  r_chunk = per;
+  splits = (a->K + per - 1) / per;
+}
+
 static int epilogue_mode(const hct_gemm_args* a) {
   if (g_nt_variant >= 1000 || a->C2) return EPI_GENERIC;
   const bool small = a->ldc * 256 < (1ll << 28) && a->ldr * 256 < (1ll << 28) && a->ldaux * 256 < (1ll << 28);
@@ -877,7 +1071,8 @@ void hct_debug_set_gemm_variant(int v) { g_nt_variant = v; }
 size_t hct_gemm_workspace_bytes(const hct_gemm_args* a) {
   if (choose_path(a) != PATH_TN) return 0;
   int splits, r_chunk;
-  tn_split(a, splits, r_chunk);
+  if (tn256_ok(a)) tn256_split(a, splits, r_chunk);
+  else tn_split(a, splits, r_chunk);
   return splits > 1 ? (size_t)splits * a->M * a->N * sizeof(float) : 0;
 }
 
@@ -915,6 +1110,29 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
     hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(tiles), dim3(256), 0, s, a->M, a->N, a->K, (const bf16*)a->A, a->lda,
                        (const bf16*)a->B, a->ldb, e);
     HCT_CHECK_LAUNCH("hct_gemm(nt)");
+    return 0;
+  }
+  if (path == PATH_TN && tn256_ok(a)) {
+    ProfScope ps(PROF_GEMM_TN, flops, s);
+    int splits, r_chunk;
+    tn256_split(a, splits, r_chunk);
+    const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256) * splits;
+    float* slab = nullptr;
+    if (splits > 1) {
+      if (workspace_bytes < (size_t)splits * a->M * a->N * sizeof(float) || !workspace) {
+        set_error("hct_gemm(tn256): workspace too small (%zu < %zu)", workspace_bytes, (size_t)splits * a->M * a->N * sizeof(float));
+        return HCT_E_WORKSPACE;
+      }
+      slab = (float*)workspace;
+    }
+    hipLaunchKernelGGL(gemm_bf16_tn256_kernel, dim3(std::min(tiles, num_cus())), dim3(512), 0, s, a->M, a->N, a->K, r_chunk,
+                       (const bf16*)a->A, a->lda, (const bf16*)a->B, a->ldb, slab, e, tiles);
+    if (slab) {
+      const int64_t total4 = (int64_t)a->M * a->N / 4;
+      const int blocks = (int)std::min<int64_t>(2048, (total4 + 255) / 256);
+      hipLaunchKernelGGL(gemm_fold_kernel, dim3(blocks), dim3(256), 0, s, slab, splits, a->M, a->N, e);
+    }
+    HCT_CHECK_LAUNCH("hct_gemm(tn256)");
     return 0;
   }
   if (path == PATH_TN) {
