@@ -48,6 +48,22 @@ def algorithmic_train_flops_per_volume(c) -> float:
     return 3.0 * fwd
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (separate passes cannot run
+    inside the timed region); None if no summary is present."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_nt256.json")))
+    if not cands:
+        return None
+    try:
+        with open(cands[-1]) as f:
+            d = json.load(f)
+        return {"hbm_bytes_per_launch": round(d["hbm_bytes_per_launch"]), "source": os.path.relpath(cands[-1], ROOT),
+                "note": "2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), gfx950 FETCH_SIZE correction applied"}
+    except Exception:
+        return None
+
+
 def _host_threads() -> int:
     """Threads to use for the CPU baseline: the CPUs this process may run on, capped at the GPU box's 16-CPU share."""
     try:
@@ -174,8 +190,9 @@ def main():
         _lib.check(lib.hct_prof_read(0, C.byref(ms), C.byref(n), C.byref(w)), "hct_prof_read")
         if n.value and ms.value > 0:
             ach = w.value / (ms.value * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_nt256_kernel<*> (all epilogue modes)", "achieved": round(ach, 2),
+                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
+                    "algorithmic_TFLOP_per_launch": round(w.value / n.value / 1e12, 4),
                     "launches_per_step": n.value // args.steps, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                     "time_share_of_step": round(ms.value * 1e-3 / elapsed, 4)}
         extra = {}
