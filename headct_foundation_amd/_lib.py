@@ -81,6 +81,7 @@ _PROTOS = {
     "hct_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_float, c_float,
                                c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "hct_debug_set_gemm_variant": (None, [c_int]),
+    "hct_debug_set_gemm_stagger": (None, [c_int]),
     "hct_prof_enable": (None, [c_int]),
     "hct_prof_reset": (None, []),
     "hct_prof_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double)]),

@@ -16,6 +16,9 @@
 
 namespace hct {
 
+static int g_w4_auto = 0;   // auto-dispatch of the 2-WG/CU variant (enabled once measured)
+static int g_store_policy = 0;  // epilogue store cache policy experiment: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1
+static int g_stagger = -1;  // -1 auto, >= 0 forced (testing)
 static int g_nt_variant = 0;  // 0 auto, 128 / 256 forced (testing); +1000*k = timing experiments
 
 struct Epilogue {
@@ -431,6 +434,10 @@ __device__ __forceinline__ f32x4 bload_bf16x4(__amdgpu_buffer_rsrc_t r, uint32_t
 // All global traffic of the specialised epilogue goes through buffer instructions: SGPR descriptor + one 32-bit lane
 // offset, so no 64-bit per-lane addresses exist (those were being spilled around every store, and each reload's
 // vmcnt(0) serialised the whole store stream: ~20 us per 256x256 tile).
+// Epilogue traffic is streamed once: non-temporal policy (aux = 2) keeps it from displacing the A/B panels that the
+// LDS-DMA stream re-reads through L2 (measured +9..16 % on the N >= 2304, K = 768 GEMMs).
+constexpr int kNT = 2;
+
 template <int MODE>
 __device__ __forceinline__ void epilogue_tile16x128_m(const Epilogue& e, const TileBufs& tb, unsigned char* patch, int lane,
                                                       int m0, int n0, int row0, int col0, int M, int N, const f32x4* acc) {
@@ -462,9 +469,9 @@ __device__ __forceinline__ void epilogue_tile16x128_m(const Epilogue& e, const T
       const int prow = (h * 4 + it) * 2;  // even row of the pair inside the 16-row patch
       v[it] = *reinterpret_cast<const f32x4*>(patch + (prow + rr) * 512 + ((cc ^ ((prow + rr) & 7)) << 4));
       const bool ok = nok && prow + rr < rows_left;
-      if (MODE == EPI_RES_F32) r[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tb.res, ok ? lane_r * 4u : OOB, (row0 + prow) * ldr * 4, 0));
+      if (MODE == EPI_RES_F32) r[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tb.res, ok ? lane_r * 4u : OOB, (row0 + prow) * ldr * 4, kNT));
       if (MODE == EPI_DGELU_BF16) {
-        const bf16x4 t = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(tb.aux, ok ? lane_x * 2u : OOB, (row0 + prow) * ldx * 2, 0));
+        const bf16x4 t = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(tb.aux, ok ? lane_x * 2u : OOB, (row0 + prow) * ldx * 2, kNT));
         r[it] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
       }
     }
@@ -477,22 +484,22 @@ __device__ __forceinline__ void epilogue_tile16x128_m(const Epilogue& e, const T
       f32x4 x = v[it] * e.alpha + bv;
       if (MODE == EPI_PLAIN_BF16) {
         bf16x4 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), tb.c, vc2, sc2, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), tb.c, vc2, sc2, kNT);
       } else if (MODE == EPI_RES_F32 || MODE == EPI_PLAIN_F32) {
         if (MODE == EPI_RES_F32) x += r[it];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), tb.c, vc4, sc4, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), tb.c, vc4, sc4, kNT);
       } else if (MODE == EPI_GELU_BF16) {
         bf16x4 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), tb.aux, vx2, sx2, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), tb.aux, vx2, sx2, kNT);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = gelu_erf(x[i]);
+        for (int i = 0; i < 4; ++i) x[i] = gelu_fast(x[i]);
         bf16x4 o2 = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o2), tb.c, vc2, sc2, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o2), tb.c, vc2, sc2, kNT);
       } else {  // EPI_DGELU_BF16
 #pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] *= dgelu_erf(r[it][i]);
+        for (int i = 0; i < 4; ++i) x[i] *= dgelu_fast(r[it][i]);
         bf16x4 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), tb.c, vc2, sc2, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), tb.c, vc2, sc2, kNT);
       }
     }
   }
@@ -504,7 +511,7 @@ __device__ __forceinline__ void epilogue_tile16x128_m(const Epilogue& e, const T
 // and under the next main loop instead of leaving the CU's matrix pipes idle.
 template <int MODE>
 __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, int K, const bf16* __restrict__ A, int64_t lda,
-                                                                 const bf16* __restrict__ B, int64_t ldb, Epilogue e, int ntiles) {
+                                                                 const bf16* __restrict__ B, int64_t ldb, Epilogue e, int ntiles, int stagger) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[163840];  // 4 stages x (A 16K | B 16K) + 32K epilogue
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ntm = (M + 255) >> 8, ntn = (N + 255) >> 8;
@@ -582,6 +589,14 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     __builtin_amdgcn_s_barrier();
   };
 
+  // De-phase the persistent workgroups: all tiles cost the same, so without this every CU reaches its epilogue at the same
+  // moment and the chip alternates between an HBM write burst (matrix pipes idle, vmcnt is in-order so the next tile
+  // cannot start until the stores drain) and a pure-MFMA phase.  Eight start phases spread the bursts over the main loops
+  // of the other CUs.
+  if (stagger > 0) {
+    const int phase = (blockIdx.x >> 3) & 7;
+    for (int i = 0; i < phase * stagger; ++i) __builtin_amdgcn_s_sleep(32);
+  }
   int vb = blockIdx.x;
   set_tile(vb);
   stage(0);
@@ -684,6 +699,165 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
       }
     }
     if (!more) break;
+  }
+}
+
+// ---- NT, two workgroups per CU: 256x128 tile, 4 waves x (64x128), 3-stage ring (72 KiB) -----------------------------
+// Same pipeline and epilogue as the 256x256 kernel, but sized so that TWO workgroups are resident on a CU (2 waves per
+// SIMD in total): while one workgroup drains its tile (LDS patch -> buffer stores; vmcnt is in-order, so a wave cannot
+// run ahead of its own stores) the other one keeps the matrix pipes busy.  Pays 1.5x the LDS-DMA bytes per FLOP of the
+// 256x256 tile, so it is used for the short-K, wide-output GEMMs whose epilogue dominates (measured crossover in
+// hct_gemm).  Ring of 3: stage t+3 reuses the buffer of stage t at the mid-stage barrier, after lgkmcnt(0).
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) gemm_bf16_nt_w4_kernel(int M, int N, int K, const bf16* __restrict__ A, int64_t lda,
+                                                                 const bf16* __restrict__ B, int64_t ldb, Epilogue e, int ntiles,
+                                                                 int stagger) {
+  constexpr int kStage = 24576;  // A 256 x 64 B | B 128 x 64 B
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * kStage];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ntm = (M + 255) >> 8, ntn = (N + 127) >> 7;
+
+  uint32_t voa[4], vob[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 16 + (lane >> 2);
+    voa[i] = (uint32_t)(row * lda * 2 + (((lane & 3) ^ swz64(row)) << 4));
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 16 + (lane >> 2);
+    vob[i] = (uint32_t)(row * ldb * 2 + (((lane & 3) ^ swz64(row)) << 4));
+  }
+  const int wm = wave;
+  const int frow = lane & 15, fchk = lane >> 4;
+  const int foff = frow * 64 + ((fchk ^ swz64(frow)) << 4);
+  const int nk = K >> 5;
+
+  __amdgpu_buffer_rsrc_t ra, rb;
+  int m0 = 0, n0 = 0;
+  auto set_tile = [&](int vb) {
+    const int nwg = ntm * ntn;
+    const int xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    const int tm = id / ntn, tn = id - tm * ntn;
+    m0 = tm << 8;
+    n0 = tn << 7;
+    ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)m0 * lda), 0, clamp_records(((int64_t)(M - m0 - 1) * lda + K) * 2), 0x00020000);
+    rb = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (int64_t)n0 * ldb), 0, clamp_records(((int64_t)(N - n0 - 1) * ldb + K) * 2), 0x00020000);
+  };
+  auto bufof = [&](int t) -> unsigned char* { return smem + (t % 3) * kStage; };
+  auto stage = [&](int t) {
+    unsigned char* base = bufof(t);
+    const uint32_t kb = (uint32_t)t * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + (wave * 4 + i) * 1024), 16, voa[i] + kb, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + 16384 + (wave * 2 + i) * 1024), 16, vob[i] + kb, 0, 0, 0);
+  };
+  f32x4 acc[4][8];
+  bf16x8 b_lo[4], b_hi[4], a0[4], a1[4];
+  auto rd_a = [&](int t, bf16x8* af) {
+    const unsigned char* sa = bufof(t) + wm * 4096 + foff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 1024);
+  };
+  auto rd_b = [&](int t, int half, bf16x8* bq) {
+    const unsigned char* sb = bufof(t) + 16384 + half * 4096 + foff;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const bf16x8*>(sb + j * 1024);
+  };
+  auto mma = [&](int half, const bf16x8* af, const bf16x8* bq) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][half * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[i][half * 4 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // own DMA retired (leaving `later` younger stages = 6 loads each in flight), every fragment read issued so far has
+  // returned (so the buffer of the current stage may be refilled right after), then barrier
+  auto land = [&](int later) {
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // the two workgroups of a CU do identical work: start the second half of the grid half a tile late so that one's
+  // epilogue falls into the other's main loop instead of both alternating in lockstep
+  if (stagger > 0 && (int)blockIdx.x >= (int)(gridDim.x >> 1))
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
+  for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+    set_tile(vb);
+    stage(0);
+    stage(1);
+    stage(2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    land(2);
+    rd_a(0, a0);
+    rd_b(0, 0, b_lo);
+    int t = 0;
+    for (; t + 4 < nk; t += 2) {
+      rd_b(t, 1, b_hi);
+      mma(0, a0, b_lo);
+      land(1);
+      stage(t + 3);
+      rd_a(t + 1, a1);
+      rd_b(t + 1, 0, b_lo);
+      mma(1, a0, b_hi);
+      rd_b(t + 1, 1, b_hi);
+      mma(0, a1, b_lo);
+      land(1);
+      stage(t + 4);
+      rd_a(t + 2, a0);
+      rd_b(t + 2, 0, b_lo);
+      mma(1, a1, b_hi);
+    }
+    rd_b(t, 1, b_hi);
+    mma(0, a0, b_lo);
+    land(1);
+    stage(t + 3);
+    rd_a(t + 1, a1);
+    rd_b(t + 1, 0, b_lo);
+    mma(1, a0, b_hi);
+    rd_b(t + 1, 1, b_hi);
+    mma(0, a1, b_lo);
+    land(1);
+    rd_a(t + 2, a0);
+    rd_b(t + 2, 0, b_lo);
+    mma(1, a1, b_hi);
+    rd_b(t + 2, 1, b_hi);
+    mma(0, a0, b_lo);
+    land(0);
+    rd_a(t + 3, a1);
+    rd_b(t + 3, 0, b_lo);
+    mma(1, a0, b_hi);
+    rd_b(t + 3, 1, b_hi);
+    mma(0, a1, b_lo);
+    mma(1, a1, b_hi);
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // ring free: reuse it for the epilogue patches (4 waves x 8 KiB)
+    {
+      unsigned char* patch = smem + wave * 8192;
+      TileBufs tb;
+      if (MODE != EPI_GENERIC) {
+        const int csz = (MODE == EPI_RES_F32 || MODE == EPI_PLAIN_F32) ? 4 : 2;
+        tb.c = tile_rsrc(e.C, e.ldc, csz, m0, n0, M, N);
+        tb.res = tile_rsrc(MODE == EPI_RES_F32 ? (const void*)e.residual : nullptr, e.ldr, 4, m0, n0, M, N);
+        tb.aux = tile_rsrc((MODE == EPI_GELU_BF16 || MODE == EPI_DGELU_BF16) ? e.aux : nullptr, e.ldaux, 2, m0, n0, M, N);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        epilogue_tile16x128_m<MODE>(e, tb, patch, lane, m0, n0, wm * 64 + i * 16, 0, M, N, acc[i]);
+    }
+    __syncthreads();  // patches dead before the next tile's DMA overwrites the ring
   }
 }
 
@@ -997,7 +1171,7 @@ static Epilogue make_epilogue(const hct_gemm_args* a) {
   e.C = a->C; e.c_dtype = a->c_dtype; e.ldc = a->ldc;
   e.C2 = a->C2; e.c2_dtype = a->c2_dtype; e.ldc2 = a->ldc2;
   e.alpha = a->alpha;
-  e.dbg = g_nt_variant >= 1000 ? g_nt_variant / 1000 : 0;
+  e.dbg = g_nt_variant >= 1000 ? g_nt_variant / 1000 : g_store_policy;
   return e;
 }
 
@@ -1067,6 +1241,7 @@ using namespace hct;
 extern "C" {
 
 void hct_debug_set_gemm_variant(int v) { g_nt_variant = v; }
+void hct_debug_set_gemm_stagger(int v) { if (v <= -100) g_store_policy = -100 - v; else g_stagger = v; }
 
 size_t hct_gemm_workspace_bytes(const hct_gemm_args* a) {
   if (choose_path(a) != PATH_TN) return 0;
@@ -1088,13 +1263,38 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
     ProfScope ps(PROF_GEMM_NT, flops, s);
     const int tiles256 = ((a->M + 255) / 256) * ((a->N + 255) / 256);
     const bool ok256 = a->K % 64 == 0 && a->K >= 128;
-    const bool big = ok256 && (g_nt_variant % 1000 == 256 || g_nt_variant == 0);
+    const bool big = ok256 && (g_nt_variant % 1000 == 256 || g_nt_variant % 1000 == 4 || g_nt_variant == 0);
     if (big) {
       const int mode = epilogue_mode(a);
+      // two-workgroups-per-CU variant for epilogue-dominated shapes (short K, wide output)
+      const bool w4 = (g_nt_variant % 1000 == 4) || (g_nt_variant == 0 && g_w4_auto && a->K <= 1024);
+      if (w4) {
+        const int tiles = ((a->M + 255) / 256) * ((a->N + 127) / 128);
+        const dim3 g4(std::min(tiles, 2 * num_cus()));
+#define HCT_NTW4(MODE_)                                                                                            \
+  hipLaunchKernelGGL(gemm_bf16_nt_w4_kernel<MODE_>, g4, dim3(256), 0, s, a->M, a->N, a->K, (const bf16*)a->A, a->lda, \
+                     (const bf16*)a->B, a->ldb, e, tiles, st4)
+        const int st4 = g_stagger >= 0 ? g_stagger : (a->K / 32) * 2 / 5;
+        switch (mode) {
+          case EPI_PLAIN_BF16: HCT_NTW4(EPI_PLAIN_BF16); break;
+          case EPI_RES_F32: HCT_NTW4(EPI_RES_F32); break;
+          case EPI_GELU_BF16: HCT_NTW4(EPI_GELU_BF16); break;
+          case EPI_DGELU_BF16: HCT_NTW4(EPI_DGELU_BF16); break;
+          default: HCT_NTW4(EPI_GENERIC); break;
+        }
+#undef HCT_NTW4
+        HCT_CHECK_LAUNCH("hct_gemm(nt_w4)");
+        return 0;
+      }
       const dim3 grid(std::min(tiles256, num_cus()));
+      // one start phase = 1/8 of a tile's main loop (nk stages x ~1000 cycles; s_sleep(32) = 2048 cycles); only when each
+      // CU runs several tiles (otherwise the delay is pure loss)
+      int stagger = 0;
+      if (g_stagger >= 0) stagger = g_stagger;
+      else if (tiles256 >= 3 * (int)grid.x) stagger = std::max(1, (a->K / 32) / 16);
 #define HCT_NT256(MODE_)                                                                                              \
   hipLaunchKernelGGL(gemm_bf16_nt256_kernel<MODE_>, grid, dim3(512), 0, s, a->M, a->N, a->K, (const bf16*)a->A, a->lda, \
-                     (const bf16*)a->B, a->ldb, e, tiles256)
+                     (const bf16*)a->B, a->ldb, e, tiles256, stagger)
       switch (mode) {
         case EPI_PLAIN_BF16: HCT_NT256(EPI_PLAIN_BF16); break;
         case EPI_RES_F32: HCT_NT256(EPI_RES_F32); break;

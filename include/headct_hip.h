@@ -250,6 +250,8 @@ int hct_prof_read(int id, double* total_ms, int64_t* launches, double* work);
 void hct_debug_force_simple_attention(int on);
 /* testing hook: force the NT GEMM tile variant (0 auto, 128, 256) */
 void hct_debug_set_gemm_variant(int v);
+/* testing hook: start-phase stagger of the persistent GEMM workgroups (-1 auto, 0 off, n = units) */
+void hct_debug_set_gemm_stagger(int v);
 
 #ifdef __cplusplus
 }

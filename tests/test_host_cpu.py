@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(lib):
     raw = C.CDLL(_lib.LIB_PATH)
     missing = [s for s in sorted(declared) if not hasattr(raw, s)]
     assert not missing, missing
-    assert set(_lib.exported_symbols()) <= declared | {"hct_debug_force_simple_attention", "hct_debug_set_gemm_variant"}
+    assert set(_lib.exported_symbols()) <= declared | {"hct_debug_force_simple_attention", "hct_debug_set_gemm_variant", "hct_debug_set_gemm_stagger"}
     assert lib.hct_version() >= 100 and lib.hct_has_mfma_kernels() == 1
 
 

@@ -63,6 +63,15 @@ def test_gemm_nt_bf16_mfma(lib, cuda, M, N, K):
     out = gemm(lib, A, B, 0, 1, M, N, K, bias=bias, residual=res)
     gen = gemm(lib, A, B, 0, 1, M, N, K, bias=bias, residual=res, force_generic=True)
     assert rel_err(out, ref) < 1e-5 and rel_err(gen, ref) < 1e-5  # exact bf16 products, fp32 accumulate
+    for variant in (128, 256, 4):  # every tuned NT kernel (2-stage 128^2, persistent 256^2, 2-WG/CU 256x128)
+        lib.hct_debug_set_gemm_variant(variant)
+        try:
+            o = gemm(lib, A, B, 0, 1, M, N, K, bias=bias, residual=res)
+            ob = gemm(lib, A, B, 0, 1, M, N, K, out_dtype=torch.bfloat16)
+        finally:
+            lib.hct_debug_set_gemm_variant(0)
+        assert rel_err(o, ref) < 1e-5, variant
+        assert rel_err(ob, A.float() @ B.float().t()) < 4e-3, variant
     # GELU epilogue with pre-activation side output, bf16 stores
     aux = torch.empty(M, N, dtype=torch.bfloat16, device=cuda)
     o2 = gemm(lib, A, B, 0, 1, M, N, K, out_dtype=torch.bfloat16, bias=bias, act=1, aux=aux)
