@@ -12,6 +12,8 @@ int attention_fwd_mfma(const void* qkv, int B, int N, int H, int dh, void* o, fl
 int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const float* lse, int B, int N, int H, int dh,
                        void* dqkv, hipStream_t s);
 int g_force_simple_attention = 0;
+extern int g_attn_row;
+extern int g_attn_dbg;
 }  // namespace hct
 
 using namespace hct;
@@ -19,7 +21,12 @@ using namespace hct;
 extern "C" {
 
 // testing hook: route bf16 attention through the simple kernels (A/B comparisons)
-void hct_debug_force_simple_attention(int on) { g_force_simple_attention = on; }
+void hct_debug_force_simple_attention(int on) {
+  if (on >= 10) { g_attn_dbg = on - 10; return; }
+  if (on >= 2) { g_force_simple_attention = 0; g_attn_row = on == 2 ? 0 : 1; return; }  // 2: online-softmax MFMA kernel, 3: full-row
+  g_force_simple_attention = on;
+  g_attn_row = 1;
+}
 
 int hct_attention_fwd(const void* qkv, int B, int N, int H, int dh, int dtype, void* o, float* lse, void* stream) {
   HCT_REQUIRE(B > 0 && N > 0 && H > 0 && dh > 0, "hct_attention_fwd: bad shape");

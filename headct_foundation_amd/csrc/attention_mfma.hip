@@ -16,6 +16,8 @@
 
 namespace hct {
 
+int g_attn_dbg = 0;  // timing experiments on the backward kernel: bit0 skip key-owner pass, bit1 skip query-owner pass
+
 namespace {
 
 constexpr int kRowBytes = 128;
@@ -140,10 +142,99 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma_kernel(const bf16* __restri
 }
 
 // ============================================================================================================
+// Forward, full-row form for short sequences (NT = Npad/16 key tiles known at compile time): per 16-query tile all
+// 2*NT Q.K^T MFMAs issue back-to-back into NT accumulators, ONE softmax over the whole row (max / exp / sum: two
+// cross-lane steps in total instead of per 32-key step), then the (NT/2)*ND P.V MFMAs.  8 waves per (batch, head).
+template <int DH, int NT>
+__global__ void __launch_bounds__(512) attn_fwd_row_kernel(const bf16* __restrict__ qkv, int N, int H, bf16* __restrict__ o,
+                                                           float* __restrict__ lse) {
+  constexpr int Npad = NT * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Kimg = smem;
+  unsigned char* Vimg = smem + Npad * kRowBytes;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int64_t rs = (int64_t)3 * H * DH;
+  const bf16* qb = qkv + (int64_t)b * N * rs + h * DH;
+  const int g = lane >> 4;
+  constexpr int ND = DH / 16;
+  constexpr int MAXT = (NT + 7) / 8;  // query tiles per wave
+  const int nqt = (N + 15) >> 4;
+  // Q fragments of all of this wave's query tiles are fetched up front, together with the K/V images, so their HBM
+  // latency is paid once per workgroup instead of once per query tile
+  bf16x8 qall[MAXT][2];
+#pragma unroll
+  for (int it = 0; it < MAXT; ++it) {
+    const int q = (wave + it * 8) * 16 + (lane & 15);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int d = ks * 32 + 8 * g;
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (q < N && d < DH) v = *reinterpret_cast<const bf16x8*>(qb + (int64_t)q * rs + d);
+      qall[it][ks] = v;
+    }
+  }
+  load_image<DH>(Kimg, qb + H * DH, rs, N, Npad, 512);
+  load_image<DH>(Vimg, qb + 2 * H * DH, rs, N, Npad, 512);
+  __syncthreads();
+  const float scale = rsqrtf((float)DH) * 1.44269504088896340736f;  // fold log2(e): softmax in base 2
+#pragma unroll
+  for (int it = 0; it < MAXT; ++it) {
+    const int qt = wave + it * 8;
+    if (qt >= nqt) break;
+    const int q = qt * 16 + (lane & 15);
+    bf16x8 qf[2] = {qall[it][0], qall[it][1]};
+    f32x4 st[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      st[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) st[t] = MFMA(frag_row(Kimg, t * 16, ks, lane), qf[ks], st[t]);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st[t][r] = (t * 16 + 4 * g + r < N) ? st[t][r] * scale : -INFINITY;
+        mx = fmaxf(mx, st[t][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float ps = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st[t][r] = __builtin_amdgcn_exp2f(st[t][r] - mx);
+        ps += st[t][r];
+      }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    f32x4 oacc[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) oacc[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int s2 = 0; s2 < NT / 2; ++s2) {
+      const bf16x8 pb = pack8(st[2 * s2], st[2 * s2 + 1]);
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) oacc[dt] = MFMA(frag_tr(Vimg, s2 * 32, s2 * 32 + 16, dt * 16, lane), pb, oacc[dt]);
+    }
+    if (q < N) {
+      const float inv = 1.0f / ps;
+      bf16* orow = o + ((int64_t)b * N + q) * (H * DH) + h * DH + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) Vec4<bf16>::store(orow + dt * 16, oacc[dt] * inv);
+      if (g == 0) lse[(int64_t)bh * N + q] = (mx + __builtin_amdgcn_logf(ps)) * 0.69314718055994530942f;  // back to natural log
+    }
+  }
+}
+
+// ============================================================================================================
 template <int DH>
 __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                             const bf16* __restrict__ d_o, const float* __restrict__ lse,
-                                                            int N, int H, int Npad, bf16* __restrict__ dqkv) {
+                                                            int N, int H, int Npad, bf16* __restrict__ dqkv, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Qimg = smem;
   unsigned char* Kimg = Qimg + Npad * kRowBytes;
@@ -184,7 +275,7 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
   const int ntile = Npad >> 4, npair = Npad >> 5;
 
   // ---- role 1: own a 16-key tile -> dK, dV -------------------------------------------------------------
-  for (int kt = wave; kt * 16 < N; kt += 8) {
+  for (int kt = wave; kt * 16 < N && !(dbg & 1); kt += 8) {
     const int key0 = kt * 16;
     bf16x8 kf[2], vf[2];
 #pragma unroll
@@ -236,7 +327,7 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
   }
 
   // ---- role 2: own a 16-query tile -> dQ -----------------------------------------------------------------
-  for (int qt = wave; qt * 16 < N; qt += 8) {
+  for (int qt = wave; qt * 16 < N && !(dbg & 2); qt += 8) {
     const int q0 = qt * 16;
     bf16x8 qf[2], dof[2];
 #pragma unroll
@@ -299,9 +390,25 @@ bool attention_mfma_supported(int N, int H, int dh) {
   return (dh == 48 || dh == 64) && bwd_lds(N) <= (size_t)kMaxLds;
 }
 
+template <int DH, int NT>
+static int launch_fwd_row(const void* qkv, int B, int N, int H, void* o, float* lse, hipStream_t s) {
+  const size_t lds = (size_t)2 * NT * 16 * kRowBytes;
+  if (int rc = set_lds(attn_fwd_row_kernel<DH, NT>, lds)) return rc;
+  hipLaunchKernelGGL((attn_fwd_row_kernel<DH, NT>), dim3(B * H), dim3(512), lds, s, (const bf16*)qkv, N, H, (bf16*)o, lse);
+  return check_hip(hipGetLastError(), "attention_fwd_row");
+}
+
+int g_attn_row = 1;  // testing hook: 0 = always the online-softmax kernel
+
 int attention_fwd_mfma(const void* qkv, int B, int N, int H, int dh, void* o, float* lse, hipStream_t s) {
   const int Npad = npad_of(N);
   const size_t lds = fwd_lds(N);
+  if (g_attn_row) {  // full-row kernels for the MAE token counts (<= 64, <= 160, <= 224, <= 288 keys)
+    const int nt = Npad / 16;
+#define HCT_ROW(DH_, NT_) if (dh == DH_ && nt <= NT_) return launch_fwd_row<DH_, NT_>(qkv, B, N, H, o, lse, s)
+    HCT_ROW(64, 4); HCT_ROW(48, 4); HCT_ROW(64, 10); HCT_ROW(48, 10); HCT_ROW(64, 14); HCT_ROW(48, 14); HCT_ROW(64, 18); HCT_ROW(48, 18);
+#undef HCT_ROW
+  }
   if (dh == 48) {
     if (int rc = set_lds(attn_fwd_mfma_kernel<48>, lds)) return rc;
     hipLaunchKernelGGL(attn_fwd_mfma_kernel<48>, dim3(B * H), dim3(256), lds, s, (const bf16*)qkv, N, H, Npad, (bf16*)o, lse);
@@ -319,11 +426,11 @@ int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const fl
   if (dh == 48) {
     if (int rc = set_lds(attn_bwd_mfma_kernel<48>, lds)) return rc;
     hipLaunchKernelGGL(attn_bwd_mfma_kernel<48>, dim3(B * H), dim3(512), lds, s, (const bf16*)qkv, (const bf16*)o,
-                       (const bf16*)d_o, lse, N, H, Npad, (bf16*)dqkv);
+                       (const bf16*)d_o, lse, N, H, Npad, (bf16*)dqkv, g_attn_dbg);
   } else {
     if (int rc = set_lds(attn_bwd_mfma_kernel<64>, lds)) return rc;
     hipLaunchKernelGGL(attn_bwd_mfma_kernel<64>, dim3(B * H), dim3(512), lds, s, (const bf16*)qkv, (const bf16*)o,
-                       (const bf16*)d_o, lse, N, H, Npad, (bf16*)dqkv);
+                       (const bf16*)d_o, lse, N, H, Npad, (bf16*)dqkv, g_attn_dbg);
   }
   return check_hip(hipGetLastError(), "attention_bwd_mfma");
 }
