@@ -24,15 +24,67 @@ constexpr int kRowBytes = 128;
 
 __device__ __forceinline__ int img_off(int r, int c) { return r * kRowBytes + ((c ^ ((r >> 1) & 7)) << 4); }
 
-// cooperative load of one operand image: rows [0,N) x DH columns from global (row stride rs elements), zero pad
+// cooperative load of one operand image: rows [0,N) x DH columns from global (row stride rs elements), zero pad.
+// Loads are issued in batches of 8 per thread BEFORE any LDS write: a plain load->write loop costs one global
+// round trip per iteration (4-7 serialized trips per image, which was ~40 % of the backward kernel).
 template <int DH>
 __device__ __forceinline__ void load_image(unsigned char* img, const bf16* __restrict__ g, int64_t rs, int N, int Npad,
                                            int nthreads) {
-  for (int idx = threadIdx.x; idx < Npad * 8; idx += nthreads) {
-    const int r = idx >> 3, c = idx & 7;
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (r < N && c * 8 < DH) v = *reinterpret_cast<const bf16x8*>(g + (int64_t)r * rs + c * 8);
-    *reinterpret_cast<bf16x8*>(img + img_off(r, c)) = v;
+  constexpr int U = 8;
+  const int total = Npad * 8;
+  for (int base = threadIdx.x; base < total; base += nthreads * U) {
+    bf16x8 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * nthreads;
+      const int r = idx >> 3, c = idx & 7;
+      v[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (idx < total && r < N && c * 8 < DH) v[u] = *reinterpret_cast<const bf16x8*>(g + (int64_t)r * rs + c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * nthreads;
+      if (idx < total) *reinterpret_cast<bf16x8*>(img + img_off(idx >> 3, idx & 7)) = v[u];
+    }
+  }
+}
+
+// delta[r] = sum_d dO[r,d] * O[r,d] and lse[r] into LDS.  8 lanes per row (one 16-B chunk each, coalesced 96/128-B row
+// reads, 3 shuffle steps) with all loads of a thread issued before their use; the old one-thread-per-row form touched 64
+// different cache lines per wave instruction and serialised 12 of them per thread.
+template <int DH>
+__device__ __forceinline__ void compute_delta(const bf16* __restrict__ ob, const bf16* __restrict__ dob, int64_t os,
+                                              const float* __restrict__ lse_row, int N, int Npad, float* sLse, float* sDel,
+                                              int nthreads) {
+  constexpr int U = 4;
+  const int total = Npad * 8;
+  for (int base = threadIdx.x; base < total; base += nthreads * U) {
+    bf16x8 a[U], d[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * nthreads;
+      const int r = idx >> 3, c = idx & 7;
+      a[u] = d[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (idx < total && r < N && c * 8 < DH) {
+        a[u] = *reinterpret_cast<const bf16x8*>(ob + (int64_t)r * os + c * 8);
+        d[u] = *reinterpret_cast<const bf16x8*>(dob + (int64_t)r * os + c * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * nthreads;
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part += (float)a[u][e] * (float)d[u][e];
+      part += __shfl_xor(part, 1, 64);
+      part += __shfl_xor(part, 2, 64);
+      part += __shfl_xor(part, 4, 64);
+      if (idx < total && (idx & 7) == 0) {
+        const int r = idx >> 3;
+        sDel[r] = r < N ? part : 0.f;
+        sLse[r] = r < N ? lse_row[r] : INFINITY;  // padded query rows: p = exp(s - inf) = 0
+      }
+    }
   }
 }
 
@@ -62,6 +114,16 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
+// (batch, head) of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs; the heads of one volume interleave
+// inside the same 128-B lines of the [B,N,3,H,dh] rows, so give every XCD a CONTIGUOUS run of (b,h) indices: the
+// workgroups resident on an XCD at one time then work on neighbouring heads and share those lines in its L2 instead of
+// each L2 fetching them again (measured: the backward's load phase ran at ~2x the algorithmic bytes).
+__device__ __forceinline__ int xcd_bh() {
+  const int n = gridDim.x, i = blockIdx.x;
+  const int xcd = i & 7, q = n >> 3, r = n & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (i >> 3);
+}
+
 // ============================================================================================================
 template <int DH>
 __global__ void __launch_bounds__(256) attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int N, int H, int Npad,
@@ -70,7 +132,7 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma_kernel(const bf16* __restri
   unsigned char* Kimg = smem;
   unsigned char* Vimg = smem + Npad * kRowBytes;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int bh = xcd_bh(), b = bh / H, h = bh - b * H;
   const int64_t rs = (int64_t)3 * H * DH;
   const bf16* qb = qkv + (int64_t)b * N * rs + h * DH;
   load_image<DH>(Kimg, qb + H * DH, rs, N, Npad, 256);
@@ -153,7 +215,7 @@ __global__ void __launch_bounds__(512) attn_fwd_row_kernel(const bf16* __restric
   unsigned char* Kimg = smem;
   unsigned char* Vimg = smem + Npad * kRowBytes;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int bh = xcd_bh(), b = bh / H, h = bh - b * H;
   const int64_t rs = (int64_t)3 * H * DH;
   const bf16* qb = qkv + (int64_t)b * N * rs + h * DH;
   const int g = lane >> 4;
@@ -243,7 +305,7 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
   float* sLse = reinterpret_cast<float*>(Dimg + Npad * kRowBytes);
   float* sDel = sLse + Npad;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int bh = xcd_bh(), b = bh / H, h = bh - b * H;
   const int64_t rs = (int64_t)3 * H * DH;
   const int64_t os = (int64_t)H * DH;
   const bf16* qb = qkv + (int64_t)b * N * rs + h * DH;
@@ -253,21 +315,7 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
   load_image<DH>(Kimg, qb + H * DH, rs, N, Npad, 512);
   load_image<DH>(Vimg, qb + 2 * H * DH, rs, N, Npad, 512);
   load_image<DH>(Dimg, dob, os, N, Npad, 512);
-  for (int r = threadIdx.x; r < Npad; r += 512) {
-    float dl = 0.f, L = INFINITY;  // padded query rows: p = exp(s - inf) = 0
-    if (r < N) {
-#pragma unroll
-      for (int c = 0; c < DH / 8; ++c) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ob + (int64_t)r * os + c * 8);
-        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dob + (int64_t)r * os + c * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dl += (float)a[e] * (float)d[e];
-      }
-      L = lse[(int64_t)bh * N + r];
-    }
-    sLse[r] = L;
-    sDel[r] = dl;
-  }
+  compute_delta<DH>(ob, dob, os, lse + (int64_t)bh * N, N, Npad, sLse, sDel, 512);
   __syncthreads();
   const float scale = rsqrtf((float)DH);
   const int g = lane >> 4;
@@ -371,6 +419,163 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
   (void)ntile;
 }
 
+// own-tile operand straight from global memory (row index on lane&15, 8 consecutive d of k-step ks), zero padded
+template <int DH>
+__device__ __forceinline__ bf16x8 gfrag(const bf16* __restrict__ base, int64_t rs, int r0, int ks, int lane, int N) {
+  const int r = r0 + (lane & 15), d = ks * 32 + 8 * (lane >> 4);
+  bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (r < N && d < DH) v = *reinterpret_cast<const bf16x8*>(base + (int64_t)r * rs + d);
+  return v;
+}
+
+// ============================================================================================================
+// Backward, two-phase LDS use: only the two STREAMED operands of a pass live in LDS (pass 1: Q and dO; pass 2: K and V),
+// the tile a wave owns comes from global memory (prefetched one tile ahead).  2 images + lse/delta = 58 KiB for 224
+// tokens, 4 waves per workgroup -> two (or three) workgroups per CU, so one workgroup's load phases (40 % of the old
+// single-phase kernel, which needed 112 KiB and ran alone on its CU) hide behind another's MFMA passes.
+template <int DH, int NW>
+__global__ void __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) attn_bwd2_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                                const bf16* __restrict__ d_o, const float* __restrict__ lse,
+                                                                int N, int H, int Npad, bf16* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* img0 = smem;
+  unsigned char* img1 = smem + Npad * kRowBytes;
+  float* sLse = reinterpret_cast<float*>(img1 + Npad * kRowBytes);
+  float* sDel = sLse + Npad;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = xcd_bh(), b = bh / H, h = bh - b * H;
+  const int64_t rs = (int64_t)3 * H * DH;
+  const int64_t os = (int64_t)H * DH;
+  const bf16* qb = qkv + (int64_t)b * N * rs + h * DH;
+  const bf16* kb = qb + H * DH;
+  const bf16* vb = qb + 2 * H * DH;
+  const bf16* ob = o + (int64_t)b * N * os + h * DH;
+  const bf16* dob = d_o + (int64_t)b * N * os + h * DH;
+  const float scale = rsqrtf((float)DH);
+  const int g = lane >> 4;
+  constexpr int ND = DH / 16;
+  const int npair = Npad >> 5;
+
+  // ---- pass 1: Q, dO streamed from LDS; the wave owns 16-key tiles (dK, dV) --------------------------------
+  bf16x8 kf[2], vf[2], kn[2], vn[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    kf[ks] = gfrag<DH>(kb, rs, wave * 16, ks, lane, N);
+    vf[ks] = gfrag<DH>(vb, rs, wave * 16, ks, lane, N);
+  }
+  load_image<DH>(img0, qb, rs, N, Npad, NW * 64);
+  load_image<DH>(img1, dob, os, N, Npad, NW * 64);
+  compute_delta<DH>(ob, dob, os, lse + (int64_t)bh * N, N, Npad, sLse, sDel, NW * 64);
+  __syncthreads();
+  for (int kt = wave; kt * 16 < N; kt += NW) {
+    const int key0 = kt * 16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {  // prefetch the next owned tile (zero beyond N)
+      kn[ks] = gfrag<DH>(kb, rs, key0 + NW * 16, ks, lane, N);
+      vn[ks] = gfrag<DH>(vb, rs, key0 + NW * 16, ks, lane, N);
+    }
+    const bool key_ok = key0 + (lane & 15) < N;
+    f32x4 dKt[ND], dVt[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) dKt[dt] = dVt[dt] = f32x4{0, 0, 0, 0};
+    for (int qp = 0; qp < npair; ++qp) {
+      f32x4 P[2], dS[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int q0 = qp * 32 + hh * 16;
+        f32x4 sacc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          sacc = MFMA(frag_row(img0, q0, ks, lane), kf[ks], sacc);  // S[q = 4g+r][key = lane&15]
+          dp = MFMA(frag_row(img1, q0, ks, lane), vf[ks], dp);      // dP[q][key]
+        }
+        const f32x4 L4 = *reinterpret_cast<const f32x4*>(sLse + q0 + 4 * g);
+        const f32x4 D4 = *reinterpret_cast<const f32x4*>(sDel + q0 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = key_ok ? __expf(sacc[r] * scale - L4[r]) : 0.f;
+          P[hh][r] = pv;
+          dS[hh][r] = pv * (dp[r] - D4[r]) * scale;
+        }
+      }
+      const bf16x8 pa = pack8(P[0], P[1]);
+      const bf16x8 dsa = pack8(dS[0], dS[1]);
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        dVt[dt] = MFMA(frag_tr(img1, qp * 32, qp * 32 + 16, dt * 16, lane), pa, dVt[dt]);   // dV^T[d][key] += dO^T.P
+        dKt[dt] = MFMA(frag_tr(img0, qp * 32, qp * 32 + 16, dt * 16, lane), dsa, dKt[dt]);  // dK^T[d][key] += Q^T.dS
+      }
+    }
+    if (key_ok) {
+      bf16* outk = dqkv + ((int64_t)b * N + key0 + (lane & 15)) * rs + H * DH + h * DH + 4 * g;
+      bf16* outv = outk + H * DH;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        Vec4<bf16>::store(outk + dt * 16, dKt[dt]);
+        Vec4<bf16>::store(outv + dt * 16, dVt[dt]);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
+  }
+
+  // ---- pass 2: K, V streamed from LDS; the wave owns 16-query tiles (dQ) -----------------------------------
+  bf16x8 qf[2], dof[2], qn[2], dn[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    qf[ks] = gfrag<DH>(qb, rs, wave * 16, ks, lane, N);
+    dof[ks] = gfrag<DH>(dob, os, wave * 16, ks, lane, N);
+  }
+  __syncthreads();  // every wave is done with the Q / dO images
+  load_image<DH>(img0, kb, rs, N, Npad, NW * 64);
+  load_image<DH>(img1, vb, rs, N, Npad, NW * 64);
+  __syncthreads();
+  for (int qt = wave; qt * 16 < N; qt += NW) {
+    const int q0 = qt * 16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qn[ks] = gfrag<DH>(qb, rs, q0 + NW * 16, ks, lane, N);
+      dn[ks] = gfrag<DH>(dob, os, q0 + NW * 16, ks, lane, N);
+    }
+    const float Lq = sLse[q0 + (lane & 15)], Dq = sDel[q0 + (lane & 15)];
+    f32x4 dQt[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) dQt[dt] = f32x4{0, 0, 0, 0};
+    for (int kp = 0; kp < npair; ++kp) {
+      f32x4 dS[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int k0 = kp * 32 + hh * 16;
+        f32x4 sacc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          sacc = MFMA(frag_row(img0, k0, ks, lane), qf[ks], sacc);  // S^T[key = 4g+r][q = lane&15]
+          dp = MFMA(frag_row(img1, k0, ks, lane), dof[ks], dp);     // dP^T[key][q]
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = (k0 + 4 * g + r < N) ? __expf(sacc[r] * scale - Lq) : 0.f;
+          dS[hh][r] = pv * (dp[r] - Dq) * scale;
+        }
+      }
+      const bf16x8 dsb = pack8(dS[0], dS[1]);
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt)
+        dQt[dt] = MFMA(frag_tr(img0, kp * 32, kp * 32 + 16, dt * 16, lane), dsb, dQt[dt]);  // dQ^T[d][q] += K^T.dS^T
+    }
+    const int q = q0 + (lane & 15);
+    if (q < N) {
+      bf16* outq = dqkv + ((int64_t)b * N + q) * rs + h * DH + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) Vec4<bf16>::store(outq + dt * 16, dQt[dt]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { qf[ks] = qn[ks]; dof[ks] = dn[ks]; }
+  }
+}
+
+inline size_t bwd2_lds(int N) { return (size_t)2 * ((N + 31) / 32 * 32) * kRowBytes + (size_t)2 * ((N + 31) / 32 * 32) * sizeof(float); }
+
 constexpr int kMaxLds = 160 * 1024;
 inline int npad_of(int N) { return (N + 31) / 32 * 32; }
 inline size_t fwd_lds(int N) { return (size_t)2 * npad_of(N) * kRowBytes; }
@@ -422,6 +627,20 @@ int attention_fwd_mfma(const void* qkv, int B, int N, int H, int dh, void* o, fl
 int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const float* lse, int B, int N, int H, int dh,
                        void* dqkv, hipStream_t s) {
   const int Npad = npad_of(N);
+  if (!(g_attn_dbg & 4)) {
+    const size_t l2 = bwd2_lds(N);
+#define HCT_BWD2(DH_, NW_)                                                                                           \
+  do {                                                                                                               \
+    if (int rc = set_lds(attn_bwd2_mfma_kernel<DH_, NW_>, l2)) return rc;                                            \
+    hipLaunchKernelGGL((attn_bwd2_mfma_kernel<DH_, NW_>), dim3(B * H), dim3(NW_ * 64), l2, s, (const bf16*)qkv,       \
+                       (const bf16*)o, (const bf16*)d_o, lse, N, H, Npad, (bf16*)dqkv);                              \
+  } while (0)
+    const bool w8 = (g_attn_dbg & 8) ? false : N > 64;  // 8 waves (16 per CU) once there are enough tiles to share
+    if (dh == 48) { if (w8) HCT_BWD2(48, 8); else HCT_BWD2(48, 4); }
+    else { if (w8) HCT_BWD2(64, 8); else HCT_BWD2(64, 4); }
+#undef HCT_BWD2
+    return check_hip(hipGetLastError(), "attention_bwd2_mfma");
+  }
   const size_t lds = bwd_lds(N);
   if (dh == 48) {
     if (int rc = set_lds(attn_bwd_mfma_kernel<48>, lds)) return rc;

@@ -111,6 +111,41 @@ BlockP add_block(hct_mae_plan* p, const std::string& pre, int d, int m, bool use
   return b;
 }
 
+// All transposed bf16 weight copies in ONE launch (82 matrices for ViT-B): table passed by value in the kernel arguments.
+constexpr int kMaxT = 112;
+struct TransposeTable {
+  int n;
+  int tile_start[kMaxT + 1];  // prefix sum of 64x64 tiles
+  int rows[kMaxT], cols[kMaxT];
+  long long src[kMaxT], dst[kMaxT];  // element offsets
+};
+
+__global__ void __launch_bounds__(256) transpose_cast_batched_kernel(const float* __restrict__ src, bf16* __restrict__ dst,
+                                                                     TransposeTable t) {
+  __shared__ float tile[64][65];
+  int lo = 0, hi = t.n;  // tile_start[lo] <= blockIdx.x < tile_start[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (t.tile_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const int rows = t.rows[lo], cols = t.cols[lo];
+  const int local = blockIdx.x - t.tile_start[lo];
+  const int tcols = (cols + 63) >> 6;
+  const int r0 = (local / tcols) * 64, c0 = (local % tcols) * 64;
+  const float* s = src + t.src[lo];
+  bf16* d = dst + t.dst[lo];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? s[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) d[(size_t)c * rows + r] = (bf16)tile[tx][i];
+  }
+}
+
 struct WsAlloc {
   size_t cur = 0;
   size_t take(size_t bytes) {
@@ -406,11 +441,24 @@ int hct_mae_refresh_weights(hct_mae_plan* p, int with_plain, void* stream) {
   HCT_REQUIRE(p && p->params_f32, "hct_mae_refresh_weights: plan not bound");
   if (p->dt != HCT_BF16) return 0;
   if (with_plain) RC(hct_cast(p->params_f32, HCT_F32, p->params_bf16, HCT_BF16, p->param_elems, stream));
+  TransposeTable t;
+  t.n = 0;
+  t.tile_start[0] = 0;
+  auto flush = [&]() -> int {
+    if (t.n == 0) return 0;
+    hipLaunchKernelGGL(transpose_cast_batched_kernel, dim3(t.tile_start[t.n]), dim3(256), 0, (hipStream_t)stream, p->params_f32,
+                       p->params_bf16_t, t);
+    t.n = 0;
+    return check_hip(hipGetLastError(), "hct_mae_refresh_weights");
+  };
   for (const auto& pi : p->params) {
     if (pi.bf16_t_offset < 0) continue;
     const int rows = (int)pi.shape[0], cols = (int)(pi.numel / pi.shape[0]);
-    RC(hct_transpose_cast(p->params_f32 + pi.offset, HCT_F32, p->params_bf16_t + pi.bf16_t_offset, HCT_BF16, rows, cols, stream));
+    t.rows[t.n] = rows; t.cols[t.n] = cols; t.src[t.n] = pi.offset; t.dst[t.n] = pi.bf16_t_offset;
+    t.tile_start[t.n + 1] = t.tile_start[t.n] + ((rows + 63) / 64) * ((cols + 63) / 64);
+    if (++t.n == kMaxT) RC(flush());
   }
+  RC(flush());
   return 0;
 }
 

@@ -31,8 +31,9 @@ for tag, N, H, dh in (("decoder", 217, 16, 48), ("encoder", 55, 12, 64)):
         (fu, ft), (bu, bt) = run(256, N, H, dh, mode)
         print(f"{tag} N={N} H={H} dh={dh} [{nm:8s}] fwd {fu:7.1f} us {ft:6.1f} TF | bwd {bu:7.1f} us {bt:6.1f} TF")
 
-for dbg, nm in ((0, "full"), (1, "skip key-owner"), (2, "skip query-owner"), (3, "loads only")):
+for dbg, nm in ((0, "two-phase 8 waves"), (8, "two-phase 4 waves"), (4, "single-phase 112 KB")):
     lib.hct_debug_force_simple_attention(10 + dbg)
-    (fu, ft), (bu, bt) = run(256, 217, 16, 48, 3)
-    print(f"decoder bwd [{nm}]: {bu:7.1f} us")
+    for tag, N, H, dh in (("decoder", 217, 16, 48), ("encoder", 55, 12, 64)):
+        (fu, ft), (bu, bt) = run(256, N, H, dh, 3)
+        print(f"{tag} bwd [{nm}]: {bu:7.1f} us {bt:6.1f} TF")
 lib.hct_debug_force_simple_attention(10)

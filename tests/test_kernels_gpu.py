@@ -129,7 +129,7 @@ def test_attention_fwd_bwd(lib, cuda, B, N, H, dh, dtype):
     (o_ref * d_o.float()).sum().backward()
     dt = _dt(qkv)
     tol = 1.5e-2 if dtype == torch.bfloat16 else 2e-5
-    for force_simple in ((0, 1, 2) if dtype == torch.bfloat16 else (0,)):  # 0 default (full-row MFMA), 1 fp32-math, 2 online-softmax MFMA
+    for force_simple in ((0, 1, 2, 14) if dtype == torch.bfloat16 else (0,)):  # 0 default, 1 fp32-math, 2 online-softmax fwd, 14 single-phase bwd
         lib.hct_debug_force_simple_attention(force_simple)
         try:
             o = torch.empty(B, N, H * dh, dtype=dtype, device=cuda)
@@ -141,6 +141,7 @@ def test_attention_fwd_bwd(lib, cuda, B, N, H, dh, dtype):
             torch.cuda.synchronize()
         finally:
             lib.hct_debug_force_simple_attention(0)
+            lib.hct_debug_force_simple_attention(10)
         assert rel_err(o, o_ref) < tol, force_simple
         assert (lse - lse_ref).abs().max() < (2e-2 if dtype == torch.bfloat16 else 1e-4)
         assert torch.isfinite(dqkv.float()).all()
