@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket the dominant kernel with HIP events")
+    ap.add_argument("--prof-all", action="store_true", help="also time TN GEMM / attention launches (adds event overhead)")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     args = ap.parse_args()
 
@@ -167,7 +168,7 @@ def main():
     prof = not args.no_prof
     if prof:
         lib.hct_prof_reset()
-        lib.hct_prof_enable(1)
+        lib.hct_prof_enable(0x1F if args.prof_all else 0x1)  # default: only the dominant kernel class (NT GEMM)
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)

@@ -9,12 +9,12 @@
 namespace hct {
 
 struct ProfRec { int id; hipEvent_t a, b; double work; };
-static bool g_prof_on = false;
+static unsigned g_prof_mask = 0;  // bit i = kernel class i is timed
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 static std::mutex g_mu;
 
-bool prof_enabled() { return g_prof_on; }
+bool prof_enabled() { return g_prof_mask != 0; }
 
 static hipEvent_t take_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
@@ -23,7 +23,7 @@ static hipEvent_t take_event() {
   return e;
 }
 
-ProfScope::ProfScope(int id, double work, hipStream_t s) : id_(id), work_(work), s_(s), on_(g_prof_on) {
+ProfScope::ProfScope(int id, double work, hipStream_t s) : id_(id), work_(work), s_(s), on_((g_prof_mask >> id) & 1u) {
   if (!on_) return;
   std::lock_guard<std::mutex> lk(g_mu);
   a_ = take_event();
@@ -43,7 +43,7 @@ using namespace hct;
 
 extern "C" {
 
-void hct_prof_enable(int on) { g_prof_on = on != 0; }
+void hct_prof_enable(int mask) { g_prof_mask = (unsigned)mask; }
 
 void hct_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_mu);

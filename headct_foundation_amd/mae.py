@@ -317,6 +317,7 @@ class MaskedAutoencoderViT(nn.Module):
         self._seg_names = [n for n, *_ in sorted(layout, key=lambda t: t[1])]
         self._plans = {}
         self._weights_version += 1
+        self._named_cache = named
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
@@ -366,7 +367,7 @@ class MaskedAutoencoderViT(nn.Module):
         """Point every trainable parameter's .grad at its slice of the flat gradient buffer.
         Returns True when some parameter already held a gradient (accumulation requested)."""
         accumulate = False
-        named = dict(self.named_parameters())
+        named = self._named_cache
         for name, off, numel, shape, rg, _ in self._layout:
             p = named[name]
             if not p.requires_grad:

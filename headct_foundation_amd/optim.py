@@ -86,9 +86,16 @@ def clip_gradients(model, clip: float, defer_to_optimizer: Optional[bool] = None
                                   0 if defer else 1, st.norms.data_ptr(), st.coef.data_ptr(), st.ws.data_ptr(),
                                   st.ws.numel(), _lib.stream_ptr()), "hct_grad_norms")
     st.coef_pending = bool(defer)
-    order = {n: i for i, n in enumerate(st.names)}
-    idx = [order[n] for n, p in m.named_parameters() if p.grad is not None]
-    return st.norms[torch.tensor(idx, device=st.norms.device, dtype=torch.long)] if idx else st.norms[:0]
+    # norms in named_parameters() order of the parameters that have a gradient; the gather index lives on the device
+    # and is rebuilt only when the set changes (building it every call would be a blocking host->device copy, i.e. a
+    # full pipeline drain per step)
+    key = tuple(p.grad is not None for p in m.parameters())
+    if getattr(st, "norm_key", None) != key:
+        order = {n: i for i, n in enumerate(st.names)}
+        idx = [order[n] for n, p in m.named_parameters() if p.grad is not None]
+        st.norm_idx = torch.tensor(idx, device=st.norms.device, dtype=torch.long)
+        st.norm_key = key
+    return st.norms[st.norm_idx]
 
 
 class HipAdamW(torch.optim.Optimizer):
@@ -104,6 +111,7 @@ class HipAdamW(torch.optim.Optimizer):
                         foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=True)
         super().__init__(params, defaults)
         self._step_count_fused = 0
+        self._step_tensor = torch.tensor(0.0)
         self._m = self._v = None
         m._managed_updates = True
 
@@ -122,17 +130,16 @@ class HipAdamW(torch.optim.Optimizer):
                 continue
             mv, vv = self._m[off:off + numel].view(shape), self._v[off:off + numel].view(shape)
             prev = old.get(id(p))
-            step = torch.tensor(float(self._step_count_fused))
             if prev:
                 mv.copy_(prev["exp_avg"]); vv.copy_(prev["exp_avg_sq"])
-                step = prev["step"] if torch.is_tensor(prev["step"]) else torch.tensor(float(prev["step"]))
-            self.state[p] = {"step": step, "exp_avg": mv, "exp_avg_sq": vv}
+            self.state[p] = {"step": self._step_tensor, "exp_avg": mv, "exp_avg_sq": vv}
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         # re-home the loaded moments into the flat buffers
         steps = [float(s["step"]) for s in self.state.values() if "step" in s]
         self._step_count_fused = int(max(steps)) if steps else 0
+        self._step_tensor = torch.tensor(float(self._step_count_fused))
         self._m = None
         self._ensure_state()
 
@@ -162,8 +169,7 @@ class HipAdamW(torch.optim.Optimizer):
             float(grp["eps"]), float(grp["weight_decay"]), self._step_count_fused,
             _lib.ptr(m._flat_bf16), _lib.stream_ptr()), "hct_adamw_step")
         st.coef_pending = False
-        for s in self.state.values():
-            s["step"] = torch.tensor(float(self._step_count_fused))
+        self._step_tensor.fill_(float(self._step_count_fused))  # one shared CPU scalar referenced by every state entry
         m.mark_weights_updated(plain_bf16_fresh=m._flat_bf16 is not None)
         return loss
 

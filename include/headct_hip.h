@@ -243,7 +243,7 @@ const void* hct_mae_plan_activation(const hct_mae_plan*, const char* name, int64
  * 3 attention fwd, 4 attention bwd.  hct_prof_read blocks until the recorded launches finished and returns
  * their summed duration, launch count and summed algorithmic work (FLOPs).
  * ------------------------------------------------------------------------------------------ */
-void hct_prof_enable(int on);
+void hct_prof_enable(int mask); /* bit i enables kernel class i; 0 = off */
 void hct_prof_reset(void);
 int hct_prof_read(int id, double* total_ms, int64_t* launches, double* work);
 /* testing hook: route bf16 attention through the fp32-math kernels */
