@@ -27,7 +27,7 @@ class GemmArgs(C.Structure):
         ("act", c_int),
         ("aux", c_void_p), ("aux_dtype", c_int), ("ldaux", c_int64),
         ("C2", c_void_p), ("c2_dtype", c_int), ("ldc2", c_int64),
-        ("alpha", c_float), ("force_generic", c_int),
+        ("alpha", c_float), ("force_generic", c_int), ("colsum_out", c_void_p),
     ]
 
 
@@ -54,6 +54,7 @@ _PROTOS = {
     "hct_version": (c_int, []),
     "hct_has_mfma_kernels": (c_int, []),
     "hct_gemm_workspace_bytes": (c_size_t, [C.POINTER(GemmArgs)]),
+    "hct_set_cu_reserve": (None, [c_int]),
     "hct_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p, c_size_t, c_void_p]),
     "hct_mask_rank": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hct_patch_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -35,6 +35,9 @@ int check_hip(hipError_t e, const char* what);
     }                                \
   } while (0)
 
+// out[d] = sum_{b < nblk} partial[b*D + d]  (fixed order; elementwise.hip)
+int fold_rows(const float* partial, int nblk, int D, float* out, hipStream_t s);
+
 inline size_t dtype_size(int dt) { return dt == HCT_BF16 ? 2 : 4; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

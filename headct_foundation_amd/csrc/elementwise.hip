@@ -242,10 +242,11 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict_
 }
 
 // out_q[d] = sum_blocks partial[blk][q][d]
-// 256 threads = 32 columns x 8 row groups; fixed summation order => deterministic
-__global__ void __launch_bounds__(256) fold_partials_kernel(const float* __restrict__ partial, int nblk, int nq_stride, int D,
+// 512 threads = 32 columns x 16 row groups; fixed summation order => deterministic
+constexpr int kFoldThreads = 512;
+__global__ void __launch_bounds__(512) fold_partials_kernel(const float* __restrict__ partial, int nblk, int nq_stride, int D,
                                                             float* o0, float* o1, float* o2) {
-  __shared__ float s_red[8][32];
+  __shared__ float s_red[16][32];
   const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int d = blockIdx.x * 32 + c;
   const int q = blockIdx.y;
@@ -253,13 +254,13 @@ __global__ void __launch_bounds__(256) fold_partials_kernel(const float* __restr
   if (out == nullptr) return;
   float acc = 0.f;
   if (d < D)
-    for (int b = rg; b < nblk; b += 8) acc += partial[((size_t)b * nq_stride + q) * D + d];
+    for (int b = rg; b < nblk; b += 16) acc += partial[((size_t)b * nq_stride + q) * D + d];
   s_red[rg][c] = acc;
   __syncthreads();
   if (rg == 0 && d < D) {
     float v = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v += s_red[i][c];
+    for (int i = 0; i < 16; ++i) v += s_red[i][c];
     out[d] = v;
   }
 }
@@ -488,6 +489,12 @@ __global__ void __launch_bounds__(256) transpose_cast_kernel(const TI* __restric
   }
 }
 
+int fold_rows(const float* partial, int nblk, int D, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((D + 31) / 32, 1), dim3(kFoldThreads), 0, s, partial, nblk, 1, D, out, (float*)nullptr,
+                     (float*)nullptr);
+  return check_hip(hipGetLastError(), "fold_rows");
+}
+
 }  // namespace hct
 
 // =================================================================================================
@@ -607,7 +614,7 @@ int hct_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
     else rc = launch_ln_bwd<float, float>(dy, x, mean, rstd, gamma, dres, rows, D, dx, dx_shadow, partial, dcolsum != nullptr, nblk, s);
   }
   if (rc) return rc;
-  hipLaunchKernelGGL(fold_partials_kernel, dim3((D + 31) / 32, dcolsum ? 3 : 2), dim3(256), 0, s, partial, nblk, 3, D,
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((D + 31) / 32, dcolsum ? 3 : 2), dim3(kFoldThreads), 0, s, partial, nblk, 3, D,
                      dgamma, dbeta, dcolsum);
   HCT_CHECK_LAUNCH("hct_layernorm_bwd");
   return 0;
@@ -643,7 +650,7 @@ int hct_decoder_assemble_bwd(const float* dy, const int32_t* ids_restore, const 
   const int nblk = min(B, kAsmBlocks);
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(decoder_assemble_bwd_reduce_kernel, dim3(nblk), dim3(threads), 0, s, dy, ids_shuffle, B, L, K, D, partial);
-  hipLaunchKernelGGL(fold_partials_kernel, dim3((D + 31) / 32, 2), dim3(256), 0, s, partial, nblk, 2, D, dmask_token,
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((D + 31) / 32, 2), dim3(kFoldThreads), 0, s, partial, nblk, 2, D, dmask_token,
                      ddec_cls, (float*)nullptr);
   HCT_CHECK_LAUNCH("hct_decoder_assemble_bwd");
   return 0;
@@ -699,7 +706,7 @@ int hct_colsum(const void* x, int dtype, int rows, int cols, int64_t ld, float* 
   HCT_DISPATCH_DTYPE(dtype, T,
                      hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3((cols + 255) / 256, chunks), dim3(256), 0, s,
                                         (const T*)x, rows, cols, ld, rpc, partial));
-  hipLaunchKernelGGL(fold_partials_kernel, dim3((cols + 31) / 32, 1), dim3(256), 0, s, partial, chunks, 1, cols, out,
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((cols + 31) / 32, 1), dim3(kFoldThreads), 0, s, partial, chunks, 1, cols, out,
                      (float*)nullptr, (float*)nullptr);
   HCT_CHECK_LAUNCH("hct_colsum");
   return 0;

@@ -31,6 +31,7 @@ struct Epilogue {
   void* C2; int c2_dtype; int64_t ldc2;
   float alpha;
   int dbg;
+  float* colsum_partial;  // [ceil(M/256)*4][N] per-(tile-row, wave-row) column sums of the output (DGELU mode), or null
 };
 
 __device__ __forceinline__ void store4(void* base, int dtype, int64_t off, f32x4 v) {
@@ -440,7 +441,8 @@ constexpr int kNT = 2;
 
 template <int MODE>
 __device__ __forceinline__ void epilogue_tile16x128_m(const Epilogue& e, const TileBufs& tb, unsigned char* patch, int lane,
-                                                      int m0, int n0, int row0, int col0, int M, int N, const f32x4* acc) {
+                                                      int m0, int n0, int row0, int col0, int M, int N, const f32x4* acc,
+                                                      f32x4* csum = nullptr) {
   if (MODE == EPI_GENERIC) {
     epilogue_tile16x128(e, patch, lane, m0 + row0, n0 + col0, M, N, acc);
     return;
@@ -498,6 +500,7 @@ __device__ __forceinline__ void epilogue_tile16x128_m(const Epilogue& e, const T
       } else {  // EPI_DGELU_BF16
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i] *= dgelu_fast(r[it][i]);
+        if (csum && ok) *csum += x;  // fused bias gradient of the Linear feeding the GELU (column sums of this output)
         bf16x4 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), tb.c, vc2, sc2, kNT);
       }
@@ -693,9 +696,17 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
         tb.res = tile_rsrc(MODE == EPI_RES_F32 ? (const void*)e.residual : nullptr, e.ldr, 4, cm0, cn0, M, N);
         tb.aux = tile_rsrc((MODE == EPI_GELU_BF16 || MODE == EPI_DGELU_BF16) ? e.aux : nullptr, e.ldaux, 2, cm0, cn0, M, N);
       }
+      f32x4 cs = {0, 0, 0, 0};
+      const bool want_cs = MODE == EPI_DGELU_BF16 && e.colsum_partial != nullptr;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        epilogue_tile16x128_m<MODE>(e, tb, patch, lane, cm0, cn0, wm * 64 + i * 16, wn * 128, M, N, acc[i]);
+        epilogue_tile16x128_m<MODE>(e, tb, patch, lane, cm0, cn0, wm * 64 + i * 16, wn * 128, M, N, acc[i], want_cs ? &cs : nullptr);
+      if (want_cs) {  // lanes l and l+32 hold the even / odd rows of the same 4 columns
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cs[q] += __shfl_xor(cs[q], 32, 64);
+        const int n = cn0 + wn * 128 + (lane & 31) * 4;
+        if (lane < 32 && n < N) Vec4<float>::store(e.colsum_partial + ((int64_t)((cm0 >> 8) * 4 + wm)) * N + n, cs);
+      }
       }
     }
     if (!more) break;
@@ -1151,7 +1162,9 @@ __global__ void __launch_bounds__(256) gemm_fold_kernel(const float* __restrict_
   }
 }
 
-static int num_cus() {
+static int g_cu_reserve = 0;  // CUs left free for concurrently running communication kernels (RCCL) -- hct_set_cu_reserve
+
+static int num_cus_total() {
   static int n = 0;
   if (n == 0) {
     int dev = 0;
@@ -1162,6 +1175,11 @@ static int num_cus() {
   return n;
 }
 
+// grid size of the persistent GEMMs: their workgroups own a CU's whole register file, so a co-running RCCL kernel could
+// only start by displacing statically scheduled workgroups (long tail); when data parallelism is active a few CUs are
+// left to it instead.
+static int num_cus() { return std::max(8, num_cus_total() - g_cu_reserve); }
+
 static bool aligned_to(const void* p, size_t a) { return p == nullptr || ((uintptr_t)p % a) == 0; }
 
 static Epilogue make_epilogue(const hct_gemm_args* a) {
@@ -1171,6 +1189,7 @@ static Epilogue make_epilogue(const hct_gemm_args* a) {
   e.C = a->C; e.c_dtype = a->c_dtype; e.ldc = a->ldc;
   e.C2 = a->C2; e.c2_dtype = a->c2_dtype; e.ldc2 = a->ldc2;
   e.alpha = a->alpha;
+  e.colsum_partial = nullptr;
   e.dbg = g_nt_variant >= 1000 ? g_nt_variant / 1000 : g_store_policy;
   return e;
 }
@@ -1240,11 +1259,18 @@ using namespace hct;
 
 extern "C" {
 
+void hct_set_cu_reserve(int n) { g_cu_reserve = n < 0 ? 0 : n; }
 void hct_debug_set_gemm_variant(int v) { g_nt_variant = v; }
 void hct_debug_set_gemm_stagger(int v) { if (v <= -100) g_store_policy = -100 - v; else g_stagger = v; }
 
+static size_t colsum_ws(const hct_gemm_args* a) {
+  if (!a->colsum_out) return 0;
+  const size_t fused = (size_t)((a->M + 255) / 256) * 4 * a->N * sizeof(float);
+  return std::max(fused, hct_colsum_workspace_bytes(a->M, a->N));
+}
+
 size_t hct_gemm_workspace_bytes(const hct_gemm_args* a) {
-  if (choose_path(a) != PATH_TN) return 0;
+  if (choose_path(a) != PATH_TN) return colsum_ws(a);
   int splits, r_chunk;
   if (tn256_ok(a)) tn256_split(a, splits, r_chunk);
   else tn_split(a, splits, r_chunk);
@@ -1258,6 +1284,19 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
   hipStream_t s = (hipStream_t)stream;
   Epilogue e = make_epilogue(a);
   const Path path = choose_path(a);
+  if (a->colsum_out) {
+    if (colsum_ws(a) > workspace_bytes || !workspace) {
+      set_error("hct_gemm: colsum_out needs %zu workspace bytes", colsum_ws(a));
+      return HCT_E_WORKSPACE;
+    }
+    HCT_REQUIRE(path != PATH_TN, "hct_gemm: colsum_out is not supported on the wgrad path");
+  }
+  // column sums of C: fused into the persistent NT kernel's DGELU epilogue, otherwise a separate pass over C
+  auto finish_colsum = [&](bool fused) -> int {
+    if (!a->colsum_out) return 0;
+    if (fused) return fold_rows((const float*)workspace, ((a->M + 255) / 256) * 4, a->N, a->colsum_out, s);
+    return hct_colsum(a->C, a->c_dtype, a->M, a->N, a->ldc, a->colsum_out, workspace, workspace_bytes, stream);
+  };
   const double flops = 2.0 * a->M * a->N * a->K;
   if (path == PATH_NT) {
     ProfScope ps(PROF_GEMM_NT, flops, s);
@@ -1284,8 +1323,10 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
         }
 #undef HCT_NTW4
         HCT_CHECK_LAUNCH("hct_gemm(nt_w4)");
-        return 0;
+        return finish_colsum(false);
       }
+      const bool fuse_cs = a->colsum_out && mode == EPI_DGELU_BF16 && a->M % 256 == 0;
+      if (fuse_cs) e.colsum_partial = (float*)workspace;
       const dim3 grid(std::min(tiles256, num_cus()));
       // one start phase = 1/8 of a tile's main loop (nk stages x ~1000 cycles; s_sleep(32) = 2048 cycles); only when each
       // CU runs several tiles (otherwise the delay is pure loss)
@@ -1304,13 +1345,13 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
       }
 #undef HCT_NT256
       HCT_CHECK_LAUNCH("hct_gemm(nt256)");
-      return 0;
+      return finish_colsum(fuse_cs);
     }
     const int tiles = ((a->M + 127) / 128) * ((a->N + 127) / 128);
     hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(tiles), dim3(256), 0, s, a->M, a->N, a->K, (const bf16*)a->A, a->lda,
                        (const bf16*)a->B, a->ldb, e);
     HCT_CHECK_LAUNCH("hct_gemm(nt)");
-    return 0;
+    return finish_colsum(false);
   }
   if (path == PATH_TN && tn256_ok(a)) {
     ProfScope ps(PROF_GEMM_TN, flops, s);
@@ -1373,7 +1414,7 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
   else HCT_GEN(float, float);
 #undef HCT_GEN
   HCT_CHECK_LAUNCH("hct_gemm(generic)");
-  return 0;
+  return finish_colsum(false);
 }
 
 }  // extern "C"

@@ -195,14 +195,17 @@ int linear_fwd(hct_mae_plan* p, const void* X, int M, int K, int w, int b, int N
 }
 
 // dX[M,K] = dY[M,N] . W[N,K]   (optionally * gelu'(aux))
-int linear_dgrad(hct_mae_plan* p, const void* dY, int M, int N, int w, int K, void* dX, int act, void* aux, hipStream_t s) {
+int linear_dgrad(hct_mae_plan* p, const void* dY, int M, int N, int w, int K, void* dX, int act, void* aux, hipStream_t s,
+                 float* colsum_out = nullptr) {
   hct_gemm_args a = base_args();
+  a.colsum_out = colsum_out;
   a.M = M; a.N = K; a.K = N;
   a.A = dY; a.a_dtype = p->dt; a.lda = N; a.transA = 0;
   if (p->dt == HCT_BF16) { a.B = p->wop_t(w); a.b_dtype = HCT_BF16; a.ldb = N; a.transB = 1; }  // W^T stored [K,N]
   else { a.B = p->wop(w); a.b_dtype = HCT_F32; a.ldb = K; a.transB = 0; }
   a.C = dX; a.c_dtype = p->dt; a.ldc = K;
   a.act = act; a.aux = aux; a.aux_dtype = p->dt; a.ldaux = K;
+  if (colsum_out) return hct_gemm(&a, p->ws + p->s_small, p->s_small_bytes, s);
   return hct_gemm(&a, nullptr, 0, s);
 }
 
@@ -262,8 +265,9 @@ int block_backward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const fl
   void* small = ws + p->s_small;
   // MLP branch
   RC(linear_wgrad(p, dhs, ws + ba.g, M, d, m, bp.fc2_w, -1, s));
-  RC(linear_dgrad(p, dhs, M, d, bp.fc2_w, m, dbig, HCT_ACT_DGELU, ws + ba.u, s));
-  RC(linear_wgrad(p, dbig, ws + ba.x2, M, m, d, bp.fc1_w, bp.fc1_b, s));
+  // d(pre-GELU) = (dh . W2) * gelu'(u); its column sums (= linear1 bias gradient) come out of the same epilogue
+  RC(linear_dgrad(p, dhs, M, d, bp.fc2_w, m, dbig, HCT_ACT_DGELU, ws + ba.u, s, p->gf(bp.fc1_b)));
+  RC(linear_wgrad(p, dbig, ws + ba.x2, M, m, d, bp.fc1_w, -1, s));
   RC(linear_dgrad(p, dbig, M, m, bp.fc1_w, d, dx, HCT_ACT_NONE, nullptr, s));
   RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + ba.h_mid), (const float*)(ws + ba.mean2), (const float*)(ws + ba.rstd2),
                        p->pf(bp.ln2_w), dh, M, d, dh, dhs, p->dt, p->gf(bp.ln2_w), p->gf(bp.ln2_b), p->gf(bp.proj_b), small,
@@ -376,6 +380,7 @@ hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int comput
   small = std::max(small, hct_colsum_workspace_bytes((int)Mx, (int)(3 * Dx)));
   small = std::max(small, hct_colsum_workspace_bytes((int)Mx, (int)mlpx));
   small = std::max(small, hct_colsum_workspace_bytes((int)Md, p->pd));
+  small = std::max(small, (size_t)((Mx + 255) / 256) * 4 * mlpx * sizeof(float));  // fused colsum partials of the dGELU dgrad
   p->s_small_bytes = small;
   p->s_small = w.take(small);
   size_t gw = 0;

@@ -40,6 +40,12 @@ class DistributedDataParallel(nn.Module):
             dist.broadcast(module._flat, src=0, group=process_group)  # DDP ctor: rank 0's parameters win
             if hasattr(module, "mark_weights_updated"):
                 module.mark_weights_updated()
+        if self.world_size > 1 and getattr(module, "_flat", None) is not None and module._flat.is_cuda:
+            # persistent GEMM workgroups fill every CU's register file: keep a few CUs free for the RCCL kernels that
+            # run concurrently with the backward (HCT_CU_RESERVE overrides; 0 disables)
+            import os
+            from . import _lib
+            _lib.load().hct_set_cu_reserve(int(os.environ.get("HCT_CU_RESERVE", "16")))
         module._grad_prescale = 1.0 / self.world_size
         module._bucket_hook = self._on_stage
         module._post_backward_hook = self._finish

@@ -68,9 +68,14 @@ typedef struct hct_gemm_args {
   void* C2; int c2_dtype; int64_t ldc2; /* optional second copy of the output (e.g. bf16 shadow) */
   float alpha;
   int force_generic;     /* testing: always take the generic kernel */
+  float* colsum_out;     /* optional [N] fp32: column sums of the OUTPUT C (the bias gradient of the Linear that produced the
+                            operand of this dgrad); fused into the epilogue where the kernel supports it */
 } hct_gemm_args;
 
 size_t hct_gemm_workspace_bytes(const hct_gemm_args* a);
+/* Leave `n` CUs out of the persistent GEMM grids (default 0) so that communication kernels (RCCL all-reduce overlapped
+ * with the backward) have somewhere to run; set by the data-parallel wrapper when world_size > 1. */
+void hct_set_cu_reserve(int n);
 int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------

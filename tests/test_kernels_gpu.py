@@ -252,3 +252,29 @@ def test_clip_and_adamw_vs_torch(lib, cuda):
         assert torch.equal(p[seg[3]:], p0[seg[3]:])  # skipped segment untouched
     assert float(coef[1]) < 1.0 and float(coef[2]) == 1.0
     assert torch.equal(shadow[:seg[3]], p[:seg[3]].to(torch.bfloat16))
+
+
+def test_gemm_dgelu_fused_colsum(lib, cuda):
+    """dgrad through GELU with the fused bias-gradient column sum (persistent NT kernel) and the separate-pass fallback."""
+    for M, N, K in ((512, 768, 256), (217 * 2, 3072, 768), (256, 256, 128)):
+        A = _rand((M, K), cuda, torch.bfloat16, 51)
+        B = _rand((N, K), cuda, torch.bfloat16, 52, 0.05)
+        aux = _rand((M, N), cuda, torch.bfloat16, 53)
+        u = aux.float().requires_grad_(True)
+        F.gelu(u).sum().backward()
+        want = (A.float() @ B.float().t()) * u.grad
+        a = GemmArgs()
+        Cm = torch.empty(M, N, dtype=torch.bfloat16, device=cuda)
+        cs = torch.full((N,), float("nan"), device=cuda)
+        a.M, a.N, a.K = M, N, K
+        a.A, a.a_dtype, a.lda, a.transA = A.data_ptr(), HCT_BF16, K, 0
+        a.B, a.b_dtype, a.ldb, a.transB = B.data_ptr(), HCT_BF16, K, 1
+        a.C, a.c_dtype, a.ldc = Cm.data_ptr(), HCT_BF16, N
+        a.act, a.aux, a.aux_dtype, a.ldaux = 2, aux.data_ptr(), HCT_BF16, N
+        a.alpha = 1.0
+        a.colsum_out = cs.data_ptr()
+        ws = torch.empty(lib.hct_gemm_workspace_bytes(C.byref(a)), dtype=torch.uint8, device=cuda)
+        _lib.check(lib.hct_gemm(C.byref(a), ws.data_ptr(), ws.numel(), _st()), "gemm+colsum")
+        assert rel_err(Cm, want) < 4e-3
+        # the fused sums are taken before bf16 rounding, the fallback after: both within bf16 noise of the fp32 sum
+        assert rel_err(cs, want.sum(0)) < 3e-3, (M, N, K)
