@@ -402,7 +402,8 @@ __device__ __forceinline__ void epilogue_tile16x128(const Epilogue& e, unsigned 
 //   EPI_GELU_BF16  : aux(bf16) = alpha*acc + bias ; C(bf16) = gelu(aux)  linear1 forward
 //   EPI_DGELU_BF16 : C(bf16) = alpha*acc * gelu'(aux(bf16))             linear2 dgrad
 //   EPI_GENERIC    : everything else (runtime flags)
-enum { EPI_GENERIC = 0, EPI_PLAIN_BF16 = 1, EPI_RES_F32 = 2, EPI_GELU_BF16 = 3, EPI_DGELU_BF16 = 4, EPI_PLAIN_F32 = 5 };
+enum { EPI_GENERIC = 0, EPI_PLAIN_BF16 = 1, EPI_RES_F32 = 2, EPI_GELU_BF16 = 3, EPI_DGELU_BF16 = 4, EPI_PLAIN_F32 = 5,
+       EPI_DGELU_CS = 6 /* DGELU + fused column sums of the output (own instance: costs registers in the epilogue) */ };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -439,10 +440,19 @@ __device__ __forceinline__ f32x4 bload_bf16x4(__amdgpu_buffer_rsrc_t r, uint32_t
 // LDS-DMA stream re-reads through L2 (measured +9..16 % on the N >= 2304, K = 768 GEMMs).
 constexpr int kNT = 2;
 
+// bias of the 4 columns this lane stores (loaded ONCE per tile, before the next tile's prefetch and before any store: a
+// load issued between stores would make its consumer wait for every older DMA and store -- vmcnt retires in order)
+__device__ __forceinline__ f32x4 tile_bias(const Epilogue& e, int n0, int col0, int lane, int N) {
+  const int n = n0 + col0 + (lane & 31) * 4;
+  f32x4 bv = {0, 0, 0, 0};
+  if (e.bias && n < N) bv = Vec4<float>::load(e.bias + n);
+  return bv;
+}
+
 template <int MODE>
 __device__ __forceinline__ void epilogue_tile16x128_m(const Epilogue& e, const TileBufs& tb, unsigned char* patch, int lane,
                                                       int m0, int n0, int row0, int col0, int M, int N, const f32x4* acc,
-                                                      f32x4* csum = nullptr) {
+                                                      f32x4 bv, f32x4* csum = nullptr) {
   if (MODE == EPI_GENERIC) {
     epilogue_tile16x128(e, patch, lane, m0 + row0, n0 + col0, M, N, acc);
     return;
@@ -453,8 +463,6 @@ __device__ __forceinline__ void epilogue_tile16x128_m(const Epilogue& e, const T
   const int rr = lane >> 5, cc = lane & 31;
   const int col = col0 + cc * 4;
   const bool nok = n0 + col < N;
-  f32x4 bv = {0, 0, 0, 0};
-  if (e.bias && nok) bv = Vec4<float>::load(e.bias + n0 + col);
   const uint32_t OOB = 0xFFFFFFF0u;
   // leading dimensions as opaque per-call scalars: keeps the (tile-invariant) offset arithmetic from being hoisted out
   // of the persistent tile loop into 30+ long-lived VGPRs (which then spill around every store)
@@ -463,23 +471,25 @@ __device__ __forceinline__ void epilogue_tile16x128_m(const Epilogue& e, const T
   const int rows_left = M - m0 - row0;
   // lane part of the offsets (elements): row rr of the pair + column; the pair index goes into the scalar offset
   const uint32_t lane_c = (uint32_t)(rr * ldc + col), lane_r = (uint32_t)(rr * ldr + col), lane_x = (uint32_t)(rr * ldx + col);
+  constexpr int EB = 2;  // rows-pairs per batch (loads of a batch first, then math + stores); 2 keeps the epilogue's
+                         // register peak low enough that nothing spills around the stores
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    f32x4 v[4], r[4];
+  for (int h = 0; h < 8 / EB; ++h) {
+    f32x4 v[EB], r[EB];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int prow = (h * 4 + it) * 2;  // even row of the pair inside the 16-row patch
+    for (int it = 0; it < EB; ++it) {
+      const int prow = (h * EB + it) * 2;  // even row of the pair inside the 16-row patch
       v[it] = *reinterpret_cast<const f32x4*>(patch + (prow + rr) * 512 + ((cc ^ ((prow + rr) & 7)) << 4));
       const bool ok = nok && prow + rr < rows_left;
       if (MODE == EPI_RES_F32) r[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tb.res, ok ? lane_r * 4u : OOB, (row0 + prow) * ldr * 4, kNT));
-      if (MODE == EPI_DGELU_BF16) {
+      if (MODE == EPI_DGELU_BF16 || MODE == EPI_DGELU_CS) {
         const bf16x4 t = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(tb.aux, ok ? lane_x * 2u : OOB, (row0 + prow) * ldx * 2, kNT));
         r[it] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
       }
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int prow = (h * 4 + it) * 2;
+    for (int it = 0; it < EB; ++it) {
+      const int prow = (h * EB + it) * 2;
       const bool ok = nok && prow + rr < rows_left;
       const uint32_t vc2 = ok ? lane_c * 2u : OOB, vc4 = ok ? lane_c * 4u : OOB, vx2 = ok ? lane_x * 2u : OOB;
       const int sc2 = (row0 + prow) * ldc * 2, sc4 = (row0 + prow) * ldc * 4, sx2 = (row0 + prow) * ldx * 2;
@@ -497,10 +507,10 @@ __device__ __forceinline__ void epilogue_tile16x128_m(const Epilogue& e, const T
         for (int i = 0; i < 4; ++i) x[i] = gelu_fast(x[i]);
         bf16x4 o2 = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o2), tb.c, vc2, sc2, kNT);
-      } else {  // EPI_DGELU_BF16
+      } else {  // EPI_DGELU_BF16 / EPI_DGELU_CS
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i] *= dgelu_fast(r[it][i]);
-        if (csum && ok) *csum += x;  // fused bias gradient of the Linear feeding the GELU (column sums of this output)
+        if (MODE == EPI_DGELU_CS && ok) *csum += x;  // fused bias gradient of the Linear feeding the GELU (column sums of this output)
         bf16x4 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), tb.c, vc2, sc2, kNT);
       }
@@ -555,8 +565,11 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = wave * 2 + i;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + c * 1024), 16, voa[i] + kb, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + 16384 + c * 1024), 16, vob[i] + kb, 0, 0, 0);
+      // the stage's K offset rides in the scalar soffset operand: the lane offsets stay tile- and stage-invariant (no
+      // per-stage VALU, nothing for the compiler to pre-compute and spill); rows past M are still dropped by the
+      // descriptor's range check on voffset
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + c * 1024), 16, voa[i], kb, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + 16384 + c * 1024), 16, vob[i], kb, 0, 0);
     }
   };
   // Software pipeline at half-stage granularity (16 live fragments: 4 A + 4 A' + 4 B-low + 4 B-high):
@@ -659,6 +672,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     mma(1, a1, b_hi);
 
     __builtin_amdgcn_s_barrier();  // every wave has its last fragments in registers: the whole ring is free
+    const f32x4 bv = MODE == EPI_GENERIC ? f32x4{0, 0, 0, 0} : tile_bias(e, cn0, wn * 128, lane, N);
     vb += gridDim.x;
     const bool more = vb < ntiles;
     if (more) {  // prefetch the next tile's first three stages (ring buffers 0..2) under this tile's epilogue
@@ -694,13 +708,13 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
         const int csz = (MODE == EPI_RES_F32) ? 4 : 2;
         tb.c = tile_rsrc(e.C, e.ldc, csz, cm0, cn0, M, N);
         tb.res = tile_rsrc(MODE == EPI_RES_F32 ? (const void*)e.residual : nullptr, e.ldr, 4, cm0, cn0, M, N);
-        tb.aux = tile_rsrc((MODE == EPI_GELU_BF16 || MODE == EPI_DGELU_BF16) ? e.aux : nullptr, e.ldaux, 2, cm0, cn0, M, N);
+        tb.aux = tile_rsrc((MODE == EPI_GELU_BF16 || MODE == EPI_DGELU_BF16 || MODE == EPI_DGELU_CS) ? e.aux : nullptr, e.ldaux, 2, cm0, cn0, M, N);
       }
       f32x4 cs = {0, 0, 0, 0};
-      const bool want_cs = MODE == EPI_DGELU_BF16 && e.colsum_partial != nullptr;
+      const bool want_cs = MODE == EPI_DGELU_CS;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        epilogue_tile16x128_m<MODE>(e, tb, patch, lane, cm0, cn0, wm * 64 + i * 16, wn * 128, M, N, acc[i], want_cs ? &cs : nullptr);
+        epilogue_tile16x128_m<MODE>(e, tb, patch, lane, cm0, cn0, wm * 64 + i * 16, wn * 128, M, N, acc[i], bv, want_cs ? &cs : nullptr);
       if (want_cs) {  // lanes l and l+32 hold the even / odd rows of the same 4 columns
 #pragma unroll
         for (int q = 0; q < 4; ++q) cs[q] += __shfl_xor(cs[q], 32, 64);
@@ -762,10 +776,10 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_nt_w4_kernel(int M, int N, i
     const uint32_t kb = (uint32_t)t * 64;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + (wave * 4 + i) * 1024), 16, voa[i] + kb, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + (wave * 4 + i) * 1024), 16, voa[i], kb, 0, 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + 16384 + (wave * 2 + i) * 1024), 16, vob[i] + kb, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + 16384 + (wave * 2 + i) * 1024), 16, vob[i], kb, 0, 0);
   };
   f32x4 acc[4][8];
   bf16x8 b_lo[4], b_hi[4], a0[4], a1[4];
@@ -857,6 +871,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_nt_w4_kernel(int M, int N, i
     __builtin_amdgcn_s_barrier();  // ring free: reuse it for the epilogue patches (4 waves x 8 KiB)
     {
       unsigned char* patch = smem + wave * 8192;
+      const f32x4 bv = MODE == EPI_GENERIC ? f32x4{0, 0, 0, 0} : tile_bias(e, n0, 0, lane, N);
       TileBufs tb;
       if (MODE != EPI_GENERIC) {
         const int csz = (MODE == EPI_RES_F32 || MODE == EPI_PLAIN_F32) ? 4 : 2;
@@ -866,7 +881,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_nt_w4_kernel(int M, int N, i
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        epilogue_tile16x128_m<MODE>(e, tb, patch, lane, m0, n0, wm * 64 + i * 16, 0, M, N, acc[i]);
+        epilogue_tile16x128_m<MODE>(e, tb, patch, lane, m0, n0, wm * 64 + i * 16, 0, M, N, acc[i], bv);
     }
     __syncthreads();  // patches dead before the next tile's DMA overwrites the ring
   }
@@ -925,6 +940,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = wave * 2 + i;
+      // NOTE: the reduction-row offset must stay in voffset here (rows past the split's end are zero-filled by the
+      // descriptor's range check, which does not see soffset)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + c * 1024), 16, voa[i] == OOB ? OOB : voa[i] + ka, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + 16384 + c * 1024), 16, vob[i] == OOB ? OOB : vob[i] + kb, 0, 0, 0);
     }
@@ -1023,6 +1040,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
     mma(1, a1, b_hi);
 
     __builtin_amdgcn_s_barrier();
+    const f32x4 bv = slab ? f32x4{0, 0, 0, 0} : tile_bias(e, cn0, wn * 128, lane, N);
     vb += gridDim.x;
     const bool more = vb < ntiles;
     if (more) {
@@ -1044,7 +1062,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
       tb.aux = tb.res;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        epilogue_tile16x128_m<EPI_PLAIN_F32>(eo, tb, patch, lane, cm0, cn0, wm * 64 + i * 16, wn * 128, M, N, acc[i]);
+        epilogue_tile16x128_m<EPI_PLAIN_F32>(eo, tb, patch, lane, cm0, cn0, wm * 64 + i * 16, wn * 128, M, N, acc[i], bv);
     }
     if (!more) break;
   }
@@ -1325,7 +1343,7 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
         HCT_CHECK_LAUNCH("hct_gemm(nt_w4)");
         return finish_colsum(false);
       }
-      const bool fuse_cs = a->colsum_out && mode == EPI_DGELU_BF16 && a->M % 256 == 0;
+      const bool fuse_cs = a->colsum_out && mode == EPI_DGELU_BF16 && a->M % 256 == 0 && !w4;
       if (fuse_cs) e.colsum_partial = (float*)workspace;
       const dim3 grid(std::min(tiles256, num_cus()));
       // one start phase = 1/8 of a tile's main loop (nk stages x ~1000 cycles; s_sleep(32) = 2048 cycles); only when each
@@ -1340,7 +1358,7 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
         case EPI_PLAIN_BF16: HCT_NT256(EPI_PLAIN_BF16); break;
         case EPI_RES_F32: HCT_NT256(EPI_RES_F32); break;
         case EPI_GELU_BF16: HCT_NT256(EPI_GELU_BF16); break;
-        case EPI_DGELU_BF16: HCT_NT256(EPI_DGELU_BF16); break;
+        case EPI_DGELU_BF16: if (fuse_cs) HCT_NT256(EPI_DGELU_CS); else HCT_NT256(EPI_DGELU_BF16); break;
         default: HCT_NT256(EPI_GENERIC); break;
       }
 #undef HCT_NT256
