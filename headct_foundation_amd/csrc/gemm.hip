@@ -518,6 +518,24 @@ __device__ __forceinline__ void epilogue_tile16x128_m(const Epilogue& e, const T
   }
 }
 
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// raw buffer descriptor in SGPRs for inline-asm buffer instructions (same 4 words make_buffer_rsrc builds)
+__device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t num_records) {
+  const uint64_t pa = (uint64_t)base;
+  return i32x4{(int)__builtin_amdgcn_readfirstlane((uint32_t)pa), (int)(__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) & 0xFFFF),
+               (int)__builtin_amdgcn_readfirstlane(num_records), 0x00020000};
+}
+
+// one 1-KiB LDS-DMA piece: lane l's 16 B from base + voffset land at LDS lds_base + 16*l (M0 carries the LDS base)
+__device__ __forceinline__ void dma16s(i32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory", "m0");
+}
+__device__ __forceinline__ void dma16(i32x4 rsrc, uint32_t lds_base, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+
 // PERSISTENT: grid = min(tiles, #CUs); each workgroup walks tiles vb = blockIdx.x, +gridDim.x, ... (same XCD every trip,
 // consecutive tiles of an XCD share an A row-panel).  At the end of a tile the first three stages of the NEXT tile are
 // issued before the epilogue, so the output stores (asynchronous) and the next tile's HBM latency drain under each other
@@ -544,7 +562,9 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
   const int foff = frow * 64 + ((fchk ^ swz64(frow)) << 4);
   const int nk = K >> 5;
 
-  __amdgpu_buffer_rsrc_t ra, rb;
+  // operand stream as inline-asm LDS-DMA (see make_srd / dma16s): keeps hipcc from draining vmcnt before LDS accesses
+  i32x4 ra, rb;
+  const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
   int m0 = 0, n0 = 0;
   auto set_tile = [&](int vb) {
     const int nwg = ntm * ntn;
@@ -556,20 +576,20 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     const bool same = MODE == EPI_GENERIC && dbg == 2;
     const bf16* Ab = A + (same ? 0 : (int64_t)m0 * lda);
     const bf16* Bb = B + (same ? 0 : (int64_t)n0 * ldb);
-    ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, clamp_records(((int64_t)(M - m0 - 1) * lda + K) * 2), 0x00020000);
-    rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, clamp_records(((int64_t)(N - n0 - 1) * ldb + K) * 2), 0x00020000);
+    ra = make_srd(Ab, clamp_records(((int64_t)(M - m0 - 1) * lda + K) * 2));
+    rb = make_srd(Bb, clamp_records(((int64_t)(N - n0 - 1) * ldb + K) * 2));
   };
   auto stage = [&](int t) {
-    unsigned char* base = smem + (t & 3) * 32768;
-    const uint32_t kb = (uint32_t)t * 64;  // 32 bf16 = 64 B per stage
+    const uint32_t base = lds0 + (t & 3) * 32768;
+    const uint32_t kb = __builtin_amdgcn_readfirstlane((uint32_t)t * 64);  // 32 bf16 = 64 B per stage
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = wave * 2 + i;
       // the stage's K offset rides in the scalar soffset operand: the lane offsets stay tile- and stage-invariant (no
       // per-stage VALU, nothing for the compiler to pre-compute and spill); rows past M are still dropped by the
       // descriptor's range check on voffset
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + c * 1024), 16, voa[i], kb, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + 16384 + c * 1024), 16, vob[i], kb, 0, 0);
+      dma16s(ra, __builtin_amdgcn_readfirstlane(base + c * 1024), voa[i], kb);
+      dma16s(rb, __builtin_amdgcn_readfirstlane(base + 16384 + c * 1024), vob[i], kb);
     }
   };
   // Software pipeline at half-stage granularity (16 live fragments: 4 A + 4 A' + 4 B-low + 4 B-high):
@@ -912,7 +932,13 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
     scol[i] = ((((slot >> 1) ^ f) << 1) | (slot & 1)) * 8;
   }
   uint32_t voa[2], vob[2];
-  __amdgpu_buffer_rsrc_t ra, rb;
+  // The operand stream of this kernel is issued as INLINE-ASM LDS-DMA.  With the builtin, hipcc (ROCm 7.2) inserts
+  // s_waitcnt vmcnt(0) between a stage's DMA issue and the ds_read_b64_tr_b16 fragment reads (it treats the transposed
+  // read as aliasing every pending LDS-DMA), which drains the whole ring every stage: the kernel then runs at one DMA
+  // round trip per 32-row stage (~1.4 us instead of ~0.45).  Ordering is enforced by the counted vmcnt waits + barriers
+  // below; compiler-generated vmcnt waits for its own loads/stores only become more conservative.
+  i32x4 ra, rb;  // buffer descriptors {base_lo, base_hi, num_records, flags} in SGPRs
+  const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
   int m0 = 0, n0 = 0, sp = 0;
   auto set_tile = [&](int vb) {
     const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7;
@@ -926,8 +952,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
     const int rows = min(R, rbeg + r_chunk) - rbeg;
     const bf16* Ab = A + (int64_t)rbeg * lda + m0;
     const bf16* Bb = B + (int64_t)rbeg * ldb + n0;
-    ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, clamp_records(((int64_t)(rows - 1) * lda + (M - m0)) * 2), 0x00020000);
-    rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, clamp_records(((int64_t)(rows - 1) * ldb + (N - n0)) * 2), 0x00020000);
+    ra = make_srd(Ab, clamp_records(((int64_t)(rows - 1) * lda + (M - m0)) * 2));
+    rb = make_srd(Bb, clamp_records(((int64_t)(rows - 1) * ldb + (N - n0)) * 2));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       voa[i] = (m0 + scol[i] < M) ? (uint32_t)((srow[i] * lda + scol[i]) * 2) : OOB;
@@ -935,15 +961,15 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
     }
   };
   auto stage = [&](int t) {
-    unsigned char* base = smem + (t & 3) * 32768;
+    const uint32_t base = lds0 + (t & 3) * 32768;
     const uint32_t ka = (uint32_t)(t * 32 * lda * 2), kb = (uint32_t)(t * 32 * ldb * 2);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = wave * 2 + i;
       // NOTE: the reduction-row offset must stay in voffset here (rows past the split's end are zero-filled by the
       // descriptor's range check, which does not see soffset)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + c * 1024), 16, voa[i] == OOB ? OOB : voa[i] + ka, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + 16384 + c * 1024), 16, vob[i] == OOB ? OOB : vob[i] + kb, 0, 0, 0);
+      dma16(ra, __builtin_amdgcn_readfirstlane(base + c * 1024), voa[i] == OOB ? OOB : voa[i] + ka);
+      dma16(rb, __builtin_amdgcn_readfirstlane(base + 16384 + c * 1024), vob[i] == OOB ? OOB : vob[i] + kb);
     }
   };
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
@@ -978,6 +1004,17 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
         acc[i][half * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[i][half * 4 + j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
+  // half of a half-stage (rows 32*part .. 32*part+31 of the wave tile): lets the 16 transposed reads of the next stage be
+  // issued as 8 + 8 around it, so no wait ever needs more than the 15 outstanding LDS ops lgkmcnt can express
+  auto mma_part = [&](int half, int part, const bf16x8* af, const bf16x8* bq) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 2 * part; i < 2 * part + 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][half * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[i][half * 4 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
   auto land = [&](int later) {
     if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -1006,35 +1043,40 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
       land(1);
       stage(t + 3);
       rd_a(t + 1, a1);
+      mma_part(1, 0, a0, b_hi);
       rd_b(t + 1, 0, b_lo);
-      mma(1, a0, b_hi);
+      mma_part(1, 1, a0, b_hi);
       rd_b(t + 1, 1, b_hi);
       mma(0, a1, b_lo);
       land(1);
       stage(t + 4);
       rd_a(t + 2, a0);
+      mma_part(1, 0, a1, b_hi);
       rd_b(t + 2, 0, b_lo);
-      mma(1, a1, b_hi);
+      mma_part(1, 1, a1, b_hi);
     }
     rd_b(t, 1, b_hi);
     mma(0, a0, b_lo);
     land(1);
     stage(t + 3);
     rd_a(t + 1, a1);
+    mma_part(1, 0, a0, b_hi);
     rd_b(t + 1, 0, b_lo);
-    mma(1, a0, b_hi);
+    mma_part(1, 1, a0, b_hi);
     rd_b(t + 1, 1, b_hi);
     mma(0, a1, b_lo);
     land(1);
     rd_a(t + 2, a0);
+    mma_part(1, 0, a1, b_hi);
     rd_b(t + 2, 0, b_lo);
-    mma(1, a1, b_hi);
+    mma_part(1, 1, a1, b_hi);
     rd_b(t + 2, 1, b_hi);
     mma(0, a0, b_lo);
     land(0);
     rd_a(t + 3, a1);
+    mma_part(1, 0, a0, b_hi);
     rd_b(t + 3, 0, b_lo);
-    mma(1, a0, b_hi);
+    mma_part(1, 1, a0, b_hi);
     rd_b(t + 3, 1, b_hi);
     mma(0, a1, b_lo);
     mma(1, a1, b_hi);
