@@ -62,5 +62,28 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_stamps_library(tag: str = "stamps", defines=("-DHCT_STAMPS",)) -> str:
+    """Diagnostic variant for scripts/stamp_gemm.py: gemm.hip with -DHCT_STAMPS (in-kernel timestamps), rest unchanged."""
+    build_library()
+    hipcc = _hipcc()
+    op = os.path.join(OBJ, f"gemm_{tag}.o")
+    r = subprocess.run([hipcc] + FLAGS + list(defines) + ["-c", os.path.join(CSRC, "gemm.hip"), "-o", op], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed (stamps):\n{r.stdout}\n{r.stderr}")
+    objs = [op if s == "gemm.hip" else os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    out = os.path.join(HERE, f"libheadct_hip_{tag}.so")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed (stamps):\n{r.stdout}\n{r.stderr}")
+    return out
+
+
 if __name__ == "__main__":
+    if "--stamps" in sys.argv:
+        print(build_stamps_library())
+        sys.exit(0)
+    if "--variant" in sys.argv:  # python -m headct_foundation_amd.build --variant TAG -DX=1 -DY=2   (diagnostic builds)
+        i = sys.argv.index("--variant")
+        print(build_stamps_library(sys.argv[i + 1], tuple(sys.argv[i + 2:])))
+        sys.exit(0)
     print(build_library(force="--force" in sys.argv, verbose=True))

@@ -440,85 +440,150 @@ __device__ __forceinline__ f32x4 bload_bf16x4(__amdgpu_buffer_rsrc_t r, uint32_t
 // LDS-DMA stream re-reads through L2 (measured +9..16 % on the N >= 2304, K = 768 GEMMs).
 constexpr int kNT = 2;
 
-// bias of the 4 columns this lane stores (loaded ONCE per tile, before the next tile's prefetch and before any store: a
-// load issued between stores would make its consumer wait for every older DMA and store -- vmcnt retires in order)
-__device__ __forceinline__ f32x4 tile_bias(const Epilogue& e, int n0, int col0, int lane, int N) {
-  const int n = n0 + col0 + (lane & 31) * 4;
-  f32x4 bv = {0, 0, 0, 0};
-  if (e.bias && n < N) bv = Vec4<float>::load(e.bias + n);
-  return bv;
-}
+// Lane -> output mapping of the specialised epilogue:
+//   bf16 outputs ("wide" modes): lane = 4 rows x 16 lanes, 8 consecutive columns (16 B) per lane -> dwordx4 stores / loads.
+//     The epilogue is store-ISSUE bound (one wave-instruction moves at most 16 B per lane whatever its width: in-kernel
+//     stamps showed ~12 B/clk/CU with dwordx2 stores, independent of the other CUs' phase), so bytes per instruction is
+//     what counts.
+//   f32 outputs: lane = 2 rows x 32 lanes, 4 consecutive columns (16 B) per lane.
+template <int MODE> struct EpiTraits {
+  static constexpr bool wide = MODE == EPI_PLAIN_BF16 || MODE == EPI_GELU_BF16 || MODE == EPI_DGELU_BF16 || MODE == EPI_DGELU_CS;
+  static constexpr bool loads = MODE == EPI_RES_F32 || MODE == EPI_DGELU_BF16 || MODE == EPI_DGELU_CS;
+  static constexpr int batches = wide ? 4 : 8;                    // row batches per 16-row patch
+  static constexpr int loads_per_rowtile = loads ? batches : 0;   // one 16-B load per lane and batch
+  static constexpr int stores_per_rowtile = MODE == EPI_GELU_BF16 ? 2 * batches : batches;
+  static constexpr int bias_ops = wide ? 2 : 1;
+  static constexpr int ops_per_tile = 4 * (loads_per_rowtile + stores_per_rowtile);  // vector-memory ops per wave and tile
+};
 
+struct TileBias { f32x4 lo, hi; };  // bias of this lane's columns (hi unused by the f32 modes)
+
+// compiler-visible bias load (kernels whose operand stream hipcc can count)
 template <int MODE>
-__device__ __forceinline__ void epilogue_tile16x128_m(const Epilogue& e, const TileBufs& tb, unsigned char* patch, int lane,
-                                                      int m0, int n0, int row0, int col0, int M, int N, const f32x4* acc,
-                                                      f32x4 bv, f32x4* csum = nullptr) {
-  if (MODE == EPI_GENERIC) {
-    epilogue_tile16x128(e, patch, lane, m0 + row0, n0 + col0, M, N, acc);
-    return;
-  }
-  const int frow = lane & 15, fchk = lane >> 4;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(patch + frow * 512 + (((j * 4 + fchk) ^ (frow & 7)) << 4)) = acc[j];
-  const int rr = lane >> 5, cc = lane & 31;
-  const int col = col0 + cc * 4;
-  const bool nok = n0 + col < N;
-  const uint32_t OOB = 0xFFFFFFF0u;
-  // leading dimensions as opaque per-call scalars: keeps the (tile-invariant) offset arithmetic from being hoisted out
-  // of the persistent tile loop into 30+ long-lived VGPRs (which then spill around every store)
-  int ldc = (int)e.ldc, ldr = (int)e.ldr, ldx = (int)e.ldaux;
-  asm volatile("" : "+s"(ldc), "+s"(ldr), "+s"(ldx));
-  const int rows_left = M - m0 - row0;
-  // lane part of the offsets (elements): row rr of the pair + column; the pair index goes into the scalar offset
-  const uint32_t lane_c = (uint32_t)(rr * ldc + col), lane_r = (uint32_t)(rr * ldr + col), lane_x = (uint32_t)(rr * ldx + col);
-  constexpr int EB = 2;  // rows-pairs per batch (loads of a batch first, then math + stores); 2 keeps the epilogue's
-                         // register peak low enough that nothing spills around the stores
-#pragma unroll
-  for (int h = 0; h < 8 / EB; ++h) {
-    f32x4 v[EB], r[EB];
-#pragma unroll
-    for (int it = 0; it < EB; ++it) {
-      const int prow = (h * EB + it) * 2;  // even row of the pair inside the 16-row patch
-      v[it] = *reinterpret_cast<const f32x4*>(patch + (prow + rr) * 512 + ((cc ^ ((prow + rr) & 7)) << 4));
-      const bool ok = nok && prow + rr < rows_left;
-      if (MODE == EPI_RES_F32) r[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tb.res, ok ? lane_r * 4u : OOB, (row0 + prow) * ldr * 4, kNT));
-      if (MODE == EPI_DGELU_BF16 || MODE == EPI_DGELU_CS) {
-        const bf16x4 t = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(tb.aux, ok ? lane_x * 2u : OOB, (row0 + prow) * ldx * 2, kNT));
-        r[it] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
-      }
+__device__ __forceinline__ TileBias tile_bias(const Epilogue& e, int n0, int col0, int lane, int N) {
+  TileBias b = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+  if (EpiTraits<MODE>::wide) {
+    const int n = n0 + col0 + (lane & 15) * 8;
+    if (e.bias && n < N) {
+      b.lo = Vec4<float>::load(e.bias + n);
+      b.hi = Vec4<float>::load(e.bias + n + 4);
     }
-#pragma unroll
-    for (int it = 0; it < EB; ++it) {
-      const int prow = (h * EB + it) * 2;
-      const bool ok = nok && prow + rr < rows_left;
-      const uint32_t vc2 = ok ? lane_c * 2u : OOB, vc4 = ok ? lane_c * 4u : OOB, vx2 = ok ? lane_x * 2u : OOB;
-      const int sc2 = (row0 + prow) * ldc * 2, sc4 = (row0 + prow) * ldc * 4, sx2 = (row0 + prow) * ldx * 2;
-      f32x4 x = v[it] * e.alpha + bv;
-      if (MODE == EPI_PLAIN_BF16) {
-        bf16x4 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), tb.c, vc2, sc2, kNT);
-      } else if (MODE == EPI_RES_F32 || MODE == EPI_PLAIN_F32) {
-        if (MODE == EPI_RES_F32) x += r[it];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), tb.c, vc4, sc4, kNT);
-      } else if (MODE == EPI_GELU_BF16) {
-        bf16x4 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), tb.aux, vx2, sx2, kNT);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = gelu_fast(x[i]);
-        bf16x4 o2 = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o2), tb.c, vc2, sc2, kNT);
-      } else {  // EPI_DGELU_BF16 / EPI_DGELU_CS
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] *= dgelu_fast(r[it][i]);
-        if (MODE == EPI_DGELU_CS && ok) *csum += x;  // fused bias gradient of the Linear feeding the GELU (column sums of this output)
-        bf16x4 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), tb.c, vc2, sc2, kNT);
-      }
-    }
+  } else {
+    const int n = n0 + col0 + (lane & 31) * 4;
+    if (e.bias && n < N) b.lo = Vec4<float>::load(e.bias + n);
   }
+  return b;
 }
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// Epilogue of one wave tile (64 rows x 128 columns = 4 row-tiles of 16), through the wave's 8 KiB LDS patch.
+// Loads (residual / pre-activation) are software-pipelined one row-tile ahead: L(i+1) is issued BEFORE the stores of
+// row-tile i, so waiting for it never drains those stores (vmcnt retires in issue order; with the loads between the
+// stores every batch paid a full store round trip: 17 us per tile for the dgelu epilogue).
+// `bias` must already be resident in registers (see the callers: a load that hipcc would have to wait for here would
+// be waited for with a count that cannot see the asm LDS-DMA prefetch, i.e. with a full drain).
+// gfx950 hazard found with in-kernel data checks (scripts/stress_gemm_epilogue.py): a buffer_store_dwordx4 that takes its
+// row offset in an SGPR soffset still reads its data VGPRs for a few cycles after issue.  hipcc's hazard recognizer only
+// pads the immediate-soffset form, so a VALU (here: the next batch's v_pk_fma_f32 into the same registers) right behind
+// the store corrupted single dwords of single lane quads -- intermittently, 0.01-1 % of the outputs of a large GEMM.
+// Four wait states behind every 16-byte store remove it (20/20 clean runs per mode and shape, where 15-20/20 failed).
+#define HCT_STORE_GUARD()              \
+  do {                                 \
+    __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_nop 3");           \
+    __builtin_amdgcn_sched_barrier(0); \
+  } while (0)
+
+template <int MODE>
+__device__ __forceinline__ void epilogue_wave64x128_m(const Epilogue& e, const TileBufs& tb, unsigned char* patch, int lane, int m0,
+                                                      int n0, int row0, int col0, int M, int N, const f32x4 (*acc)[8], const TileBias& bias,
+                                                      f32x4* csum = nullptr) {
+  typedef EpiTraits<MODE> T;
+  // the lane id as an opaque per-call value: every LDS patch address and store offset below is then recomputed here (a few
+  // VALU per tile) instead of being hoisted out of the persistent tile loop into ~20 VGPRs that live across the main
+  // loop, where the register file is full -- hipcc spilled them and reloaded with s_waitcnt vmcnt(0) at the top of every
+  // tile, draining the previous tile's stores and the prefetched stages before the first MFMA
+  asm volatile("" : "+v"(lane));
+  const int frow = lane & 15, fchk = lane >> 4;
+  constexpr int RB = T::wide ? 4 : 2;             // rows per batch
+  const int rr = T::wide ? (lane >> 4) : (lane >> 5), cc = T::wide ? (lane & 15) : (lane & 31);
+  const int col = col0 + cc * (T::wide ? 8 : 4);
+  const bool nok = n0 + col < N;
+  const uint32_t OOB = 0xFFFFFFF0u;
+  // leading dimensions as opaque per-call scalars: keeps the (tile-invariant) offset arithmetic from being hoisted out
+  // of the persistent tile loop into long-lived VGPRs
+  int ldc = (int)e.ldc, ldr = (int)e.ldr, ldx = (int)e.ldaux;
+  asm volatile("" : "+s"(ldc), "+s"(ldr), "+s"(ldx));
+  const int rows_left = M - m0 - row0;
+  // lane part of the offsets (elements); the batch's first row goes into the scalar offset
+  const uint32_t lane_c = (uint32_t)(rr * ldc + col), lane_r = (uint32_t)(rr * ldr + col), lane_x = (uint32_t)(rr * ldx + col);
+
+  u32x4 ld[2][T::loads ? T::batches : 1];
+  auto issue_loads = [&](int i) {
+    if (!T::loads) return;
+#pragma unroll
+    for (int it = 0; it < T::batches; ++it) {
+      const int prow = i * 16 + it * RB;  // first row of the batch inside the wave tile
+      const bool ok = nok && prow + rr < rows_left;
+      if (MODE == EPI_RES_F32) ld[i & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(tb.res, ok ? lane_r * 4u : OOB, (row0 + prow) * ldr * 4, kNT);
+      else ld[i & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(tb.aux, ok ? lane_x * 2u : OOB, (row0 + prow) * ldx * 2, kNT);
+    }
+  };
+  issue_loads(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(patch + frow * 512 + (((j * 4 + fchk) ^ (frow & 7)) << 4)) = acc[i][j];
+    if (i < 3) issue_loads(i + 1);
+#pragma unroll
+    for (int it = 0; it < T::batches; ++it) {
+      const int pr = it * RB + rr;        // row inside the 16-row patch
+      const int prow = i * 16 + it * RB;  // batch's first row inside the wave tile
+      const bool ok = nok && prow + rr < rows_left;
+      if (T::wide) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(patch + pr * 512 + (((2 * cc) ^ (pr & 7)) << 4));
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(patch + pr * 512 + (((2 * cc + 1) ^ (pr & 7)) << 4));
+        f32x4 x0 = v0 * e.alpha + bias.lo, x1 = v1 * e.alpha + bias.hi;
+        const uint32_t vc = ok ? lane_c * 2u : OOB, vx = ok ? lane_x * 2u : OOB;
+        const int sc = (row0 + prow) * ldc * 2, sx = (row0 + prow) * ldx * 2;
+        auto pack = [](f32x4 a, f32x4 b) {
+          bf16x8 o = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+          return __builtin_bit_cast(u32x4, o);
+        };
+        if (MODE == EPI_GELU_BF16) {
+          __builtin_amdgcn_raw_buffer_store_b128(pack(x0, x1), tb.aux, vx, sx, kNT);
+          HCT_STORE_GUARD();
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            x0[q] = gelu_fast(x0[q]);
+            x1[q] = gelu_fast(x1[q]);
+          }
+        } else if (MODE == EPI_DGELU_BF16 || MODE == EPI_DGELU_CS) {
+          const bf16x8 t = __builtin_bit_cast(bf16x8, ld[i & 1][it]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            x0[q] *= dgelu_fast((float)t[q]);
+            x1[q] *= dgelu_fast((float)t[4 + q]);
+          }
+          if (MODE == EPI_DGELU_CS && ok) {  // fused bias gradient of the Linear feeding the GELU (column sums of this output)
+            csum[0] += x0;
+            csum[1] += x1;
+          }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(pack(x0, x1), tb.c, vc, sc, kNT);
+        HCT_STORE_GUARD();
+      } else {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(patch + pr * 512 + ((cc ^ (pr & 7)) << 4));
+        f32x4 x = v * e.alpha + bias.lo;
+        if (MODE == EPI_RES_F32) x += __builtin_bit_cast(f32x4, ld[i & 1][it]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), tb.c, ok ? lane_c * 4u : OOB, (row0 + prow) * ldc * 4, kNT);
+        HCT_STORE_GUARD();
+      }
+    }
+  }
+}
+
 
 // raw buffer descriptor in SGPRs for inline-asm buffer instructions (same 4 words make_buffer_rsrc builds)
 __device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t num_records) {
@@ -535,6 +600,23 @@ __device__ __forceinline__ void dma16s(i32x4 rsrc, uint32_t lds_base, uint32_t v
 __device__ __forceinline__ void dma16(i32x4 rsrc, uint32_t lds_base, uint32_t voff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc) : "memory", "m0");
 }
+
+// Diagnostic build only (-DHCT_STAMPS, scripts/stamp_gemm.py; never part of libheadct_hip.so): wave 0 of every workgroup
+// records s_memrealtime (100 MHz, chip-global) at four points of each tile into one VGPR (lane = slot) and stores it once
+// when the workgroup exits.
+#ifdef HCT_STAMPS
+__device__ uint32_t* g_stamp_ptr = nullptr;
+#define HCT_STAMP(k)                                                                                   \
+  do {                                                                                                 \
+    unsigned long long t_;                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    stamps = lane == ((tile_i * 4 + (k)) & 63) ? (uint32_t)t_ : stamps;                                \
+  } while (0)
+#else
+#define HCT_STAMP(k)
+#endif
 
 // PERSISTENT: grid = min(tiles, #CUs); each workgroup walks tiles vb = blockIdx.x, +gridDim.x, ... (same XCD every trip,
 // consecutive tiles of an XCD share an A row-panel).  At the end of a tile the first three stages of the NEXT tile are
@@ -580,16 +662,16 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     rb = make_srd(Bb, clamp_records(((int64_t)(N - n0 - 1) * ldb + K) * 2));
   };
   auto stage = [&](int t) {
-    const uint32_t base = lds0 + (t & 3) * 32768;
-    const uint32_t kb = __builtin_amdgcn_readfirstlane((uint32_t)t * 64);  // 32 bf16 = 64 B per stage
+    const uint32_t base = lds0 + (t & 3) * 32768;  // wave-uniform by construction (wave is a readfirstlane result): SALU only
+    const uint32_t kb = (uint32_t)t * 64;          // 32 bf16 = 64 B per stage
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = wave * 2 + i;
       // the stage's K offset rides in the scalar soffset operand: the lane offsets stay tile- and stage-invariant (no
       // per-stage VALU, nothing for the compiler to pre-compute and spill); rows past M are still dropped by the
       // descriptor's range check on voffset
-      dma16s(ra, __builtin_amdgcn_readfirstlane(base + c * 1024), voa[i], kb);
-      dma16s(rb, __builtin_amdgcn_readfirstlane(base + 16384 + c * 1024), vob[i], kb);
+      dma16s(ra, base + c * 1024, voa[i], kb);
+      dma16s(rb, base + 16384 + c * 1024, vob[i], kb);
     }
   };
   // Software pipeline at half-stage granularity (16 live fragments: 4 A + 4 A' + 4 B-low + 4 B-high):
@@ -624,6 +706,18 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
+  // The first three waits of a tile that follows another tile: the previous epilogue's loads/stores (kEpiOps per wave,
+  // all issued unconditionally, OOB-predicated) are YOUNGER than the prefetched stages 0..2, and vmcnt retires in order,
+  // so "stage s landed" = "all but (younger stages + kEpiOps) retired".  Waiting with the plain counts would hold the
+  // tile's first MFMAs until the whole store burst of the previous tile has drained to HBM.
+  constexpr int kEpiOps = MODE == EPI_GENERIC ? 0 : EpiTraits<MODE>::ops_per_tile;
+  auto land_after_epilogue = [&](int later_stages) {  // later_stages = 2 (stage 0) or 1 (stages 1, 2)
+    constexpr int c2 = (8 + kEpiOps) > 63 ? 63 : (8 + kEpiOps), c1 = (4 + kEpiOps) > 63 ? 63 : (4 + kEpiOps);
+    if (later_stages == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(c2) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(c1) : "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  bool after_epi = false;  // wave-uniform: this tile was prefetched under a previous tile's epilogue
 
   // De-phase the persistent workgroups: all tiles cost the same, so without this every CU reaches its epilogue at the same
   // moment and the chip alternates between an HBM write burst (matrix pipes idle, vmcnt is in-order so the next tile
@@ -633,12 +727,17 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     const int phase = (blockIdx.x >> 3) & 7;
     for (int i = 0; i < phase * stagger; ++i) __builtin_amdgcn_s_sleep(32);
   }
+#ifdef HCT_STAMPS
+  uint32_t stamps = 0;
+  int tile_i = 0;
+#endif
   int vb = blockIdx.x;
   set_tile(vb);
   stage(0);
   stage(1);
   stage(2);
   while (true) {
+    HCT_STAMP(0);
     const int cm0 = m0, cn0 = n0;  // tile being computed (set_tile below moves m0/n0 to the next one)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -646,21 +745,23 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
     // nk is even and >= 4 (host dispatch: K % 64 == 0, K >= 128): steady-state loop without conditionals + static tail.
     // vmcnt(8) here also covers the previous tile's epilogue stores (older than the three prefetched stages).
-    land(2);
+    const bool relax = after_epi && MODE != EPI_GENERIC && nk >= 6 && stagger != -7;
+    if (relax) land_after_epilogue(2); else land(2);
+    HCT_STAMP(1);
     rd_a(0, a0);
     rd_b(0, 0, b_lo);
     int t = 0;
     for (; t + 4 < nk; t += 2) {
       rd_b(t, 1, b_hi);
       mma(0, a0, b_lo);
-      land(1);
+      if (relax && t == 0) land_after_epilogue(1); else land(1);
       stage(t + 3);
       rd_a(t + 1, a1);
       rd_b(t + 1, 0, b_lo);
       mma(1, a0, b_hi);
       rd_b(t + 1, 1, b_hi);
       mma(0, a1, b_lo);
-      land(1);
+      if (relax && t == 0) land_after_epilogue(1); else land(1);
       stage(t + 4);
       rd_a(t + 2, a0);
       rd_b(t + 2, 0, b_lo);
@@ -692,7 +793,15 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     mma(1, a1, b_hi);
 
     __builtin_amdgcn_s_barrier();  // every wave has its last fragments in registers: the whole ring is free
-    const f32x4 bv = MODE == EPI_GENERIC ? f32x4{0, 0, 0, 0} : tile_bias(e, cn0, wn * 128, lane, N);
+    HCT_STAMP(2);
+    // Bias of this lane's columns, loaded and pinned as resident BEFORE the prefetch: nothing else is outstanding here, so
+    // the wait costs one L2 round trip.  hipcc cannot count the asm LDS-DMA ops, so a wait it generated for this load
+    // after the prefetch would be a vmcnt(0) -- the epilogue would start only when the whole prefetch has landed.
+    TileBias bv = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    if (MODE != EPI_GENERIC) {
+      bv = tile_bias<MODE>(e, cn0, wn * 128, lane, N);
+      asm volatile("" : "+v"(bv.lo), "+v"(bv.hi));
+    }
     vb += gridDim.x;
     const bool more = vb < ntiles;
     if (more) {  // prefetch the next tile's first three stages (ring buffers 0..2) under this tile's epilogue
@@ -701,6 +810,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
       stage(1);
       stage(2);
     }
+    after_epi = true;
     if (MODE == EPI_GENERIC && dbg == 1) {  // timing experiment: no output traffic (keep the accumulators alive)
       float sacc = 0.f;
 #pragma unroll
@@ -730,21 +840,39 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
         tb.res = tile_rsrc(MODE == EPI_RES_F32 ? (const void*)e.residual : nullptr, e.ldr, 4, cm0, cn0, M, N);
         tb.aux = tile_rsrc((MODE == EPI_GELU_BF16 || MODE == EPI_DGELU_BF16 || MODE == EPI_DGELU_CS) ? e.aux : nullptr, e.ldaux, 2, cm0, cn0, M, N);
       }
-      f32x4 cs = {0, 0, 0, 0};
-      const bool want_cs = MODE == EPI_DGELU_CS;
+      if (MODE == EPI_GENERIC) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        epilogue_tile16x128_m<MODE>(e, tb, patch, lane, cm0, cn0, wm * 64 + i * 16, wn * 128, M, N, acc[i], bv, want_cs ? &cs : nullptr);
-      if (want_cs) {  // lanes l and l+32 hold the even / odd rows of the same 4 columns
+        for (int i = 0; i < 4; ++i) epilogue_tile16x128(e, patch, lane, cm0 + wm * 64 + i * 16, cn0 + wn * 128, M, N, acc[i]);
+      } else {
+        f32x4 cs[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+        epilogue_wave64x128_m<MODE>(e, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv, cs);
+        if (MODE == EPI_DGELU_CS) {  // lanes l, l+16, l+32, l+48 hold 4 different rows of the same 8 columns
 #pragma unroll
-        for (int q = 0; q < 4; ++q) cs[q] += __shfl_xor(cs[q], 32, 64);
-        const int n = cn0 + wn * 128 + (lane & 31) * 4;
-        if (lane < 32 && n < N) Vec4<float>::store(e.colsum_partial + ((int64_t)((cm0 >> 8) * 4 + wm)) * N + n, cs);
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              cs[h][q] += __shfl_xor(cs[h][q], 16, 64);
+              cs[h][q] += __shfl_xor(cs[h][q], 32, 64);
+            }
+          const int n = cn0 + wn * 128 + (lane & 15) * 8;
+          if (lane < 16 && n < N) {
+            float* dst = e.colsum_partial + ((int64_t)((cm0 >> 8) * 4 + wm)) * N + n;
+            Vec4<float>::store(dst, cs[0]);
+            Vec4<float>::store(dst + 4, cs[1]);
+          }
+        }
       }
       }
     }
+    HCT_STAMP(3);
+#ifdef HCT_STAMPS
+    ++tile_i;
+#endif
     if (!more) break;
   }
+#ifdef HCT_STAMPS
+  if (g_stamp_ptr && wave == 0) g_stamp_ptr[blockIdx.x * 64 + lane] = stamps;
+#endif
 }
 
 // ---- NT, two workgroups per CU: 256x128 tile, 4 waves x (64x128), 3-stage ring (72 KiB) -----------------------------
@@ -891,7 +1019,6 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_nt_w4_kernel(int M, int N, i
     __builtin_amdgcn_s_barrier();  // ring free: reuse it for the epilogue patches (4 waves x 8 KiB)
     {
       unsigned char* patch = smem + wave * 8192;
-      const f32x4 bv = MODE == EPI_GENERIC ? f32x4{0, 0, 0, 0} : tile_bias(e, n0, 0, lane, N);
       TileBufs tb;
       if (MODE != EPI_GENERIC) {
         const int csz = (MODE == EPI_RES_F32 || MODE == EPI_PLAIN_F32) ? 4 : 2;
@@ -899,9 +1026,13 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_nt_w4_kernel(int M, int N, i
         tb.res = tile_rsrc(MODE == EPI_RES_F32 ? (const void*)e.residual : nullptr, e.ldr, 4, m0, n0, M, N);
         tb.aux = tile_rsrc((MODE == EPI_GELU_BF16 || MODE == EPI_DGELU_BF16) ? e.aux : nullptr, e.ldaux, 2, m0, n0, M, N);
       }
+      if (MODE == EPI_GENERIC) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        epilogue_tile16x128_m<MODE>(e, tb, patch, lane, m0, n0, wm * 64 + i * 16, 0, M, N, acc[i], bv);
+        for (int i = 0; i < 4; ++i) epilogue_tile16x128(e, patch, lane, m0 + wm * 64 + i * 16, n0, M, N, acc[i]);
+      } else {
+        TileBias bv = tile_bias<MODE>(e, n0, 0, lane, N);
+        epilogue_wave64x128_m<MODE>(e, tb, patch, lane, m0, n0, wm * 64, 0, M, N, acc, bv);
+      }
     }
     __syncthreads();  // patches dead before the next tile's DMA overwrites the ring
   }
@@ -1082,7 +1213,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
     mma(1, a1, b_hi);
 
     __builtin_amdgcn_s_barrier();
-    const f32x4 bv = slab ? f32x4{0, 0, 0, 0} : tile_bias(e, cn0, wn * 128, lane, N);
+    TileBias bv = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    if (!slab) bv = tile_bias<EPI_PLAIN_F32>(e, cn0, wn * 128, lane, N);
     vb += gridDim.x;
     const bool more = vb < ntiles;
     if (more) {
@@ -1102,9 +1234,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
       tb.c = tile_rsrc(eo.C, eo.ldc, 4, cm0, cn0, M, N);
       tb.res = tile_rsrc(nullptr, 0, 4, cm0, cn0, M, N);
       tb.aux = tb.res;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        epilogue_tile16x128_m<EPI_PLAIN_F32>(eo, tb, patch, lane, cm0, cn0, wm * 64 + i * 16, wn * 128, M, N, acc[i], bv);
+      epilogue_wave64x128_m<EPI_PLAIN_F32>(eo, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv);
     }
     if (!more) break;
   }
@@ -1294,6 +1424,9 @@ static int epilogue_mode(const hct_gemm_args* a) {
   if (g_nt_variant >= 1000 || a->C2) return EPI_GENERIC;
   const bool small = a->ldc * 256 < (1ll << 28) && a->ldr * 256 < (1ll << 28) && a->ldaux * 256 < (1ll << 28);
   if (!small) return EPI_GENERIC;
+  // bf16 outputs are stored 8 columns (16 B) per lane
+  auto wide_ok = [](const void* p, int64_t ld) { return p == nullptr || (ld % 8 == 0 && aligned_to(p, 16)); };
+  if (a->c_dtype == HCT_BF16 && !(a->N % 8 == 0 && wide_ok(a->C, a->ldc) && wide_ok(a->aux, a->ldaux))) return EPI_GENERIC;
   if (a->act == HCT_ACT_NONE && !a->residual && a->c_dtype == HCT_BF16) return EPI_PLAIN_BF16;
   if (a->act == HCT_ACT_NONE && a->residual && a->c_dtype == HCT_F32) return EPI_RES_F32;
   if (a->act == HCT_ACT_GELU && !a->residual && a->c_dtype == HCT_BF16 && a->aux && a->aux_dtype == HCT_BF16) return EPI_GELU_BF16;
@@ -1321,6 +1454,11 @@ extern "C" {
 
 void hct_set_cu_reserve(int n) { g_cu_reserve = n < 0 ? 0 : n; }
 void hct_debug_set_gemm_variant(int v) { g_nt_variant = v; }
+#ifdef HCT_STAMPS
+int hct_debug_set_stamp_buffer(void* p) {  // >= 64 * grid uint32 (diagnostic build only)
+  return hct::check_hip(hipMemcpyToSymbol(HIP_SYMBOL(hct::g_stamp_ptr), &p, sizeof(p)), "stamp buffer");
+}
+#endif
 void hct_debug_set_gemm_stagger(int v) { if (v <= -100) g_store_policy = -100 - v; else g_stagger = v; }
 
 static size_t colsum_ws(const hct_gemm_args* a) {
@@ -1391,7 +1529,7 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
       // one start phase = 1/8 of a tile's main loop (nk stages x ~1000 cycles; s_sleep(32) = 2048 cycles); only when each
       // CU runs several tiles (otherwise the delay is pure loss)
       int stagger = 0;
-      if (g_stagger >= 0) stagger = g_stagger;
+      if (g_stagger >= 0 || g_stagger == -7) stagger = g_stagger;  // -7: no stagger, no relaxed waits (diagnostics)
       else if (tiles256 >= 3 * (int)grid.x) stagger = std::max(1, (a->K / 32) / 16);
 #define HCT_NT256(MODE_)                                                                                              \
   hipLaunchKernelGGL(gemm_bf16_nt256_kernel<MODE_>, grid, dim3(512), 0, s, a->M, a->N, a->K, (const bf16*)a->A, a->lda, \
