@@ -498,7 +498,7 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 template <int MODE>
 __device__ __forceinline__ void epilogue_wave64x128_m(const Epilogue& e, const TileBufs& tb, unsigned char* patch, int lane, int m0,
                                                       int n0, int row0, int col0, int M, int N, const f32x4 (*acc)[8], const TileBias& bias,
-                                                      f32x4* csum = nullptr) {
+                                                      f32x4& cs0, f32x4& cs1) {
   typedef EpiTraits<MODE> T;
   // the lane id as an opaque per-call value: every LDS patch address and store offset below is then recomputed here (a few
   // VALU per tile) instead of being hoisted out of the persistent tile loop into ~20 VGPRs that live across the main
@@ -520,22 +520,25 @@ __device__ __forceinline__ void epilogue_wave64x128_m(const Epilogue& e, const T
   const uint32_t lane_c = (uint32_t)(rr * ldc + col), lane_r = (uint32_t)(rr * ldr + col), lane_x = (uint32_t)(rr * ldx + col);
 
   u32x4 ld[2][T::loads ? T::batches : 1];
-  auto issue_loads = [&](int i) {
+  // f32 mode: 8 loads of 4 registers per row-tile; the look-ahead is issued in two halves (second half once half of the
+  // current row-tile's registers are free) so the double buffer peaks at 48 registers, not 64 (which spilled an accumulator)
+  constexpr int kHalf = T::wide ? T::batches : T::batches / 2;
+  auto issue_loads = [&](int i, int first, int last) {
     if (!T::loads) return;
 #pragma unroll
-    for (int it = 0; it < T::batches; ++it) {
+    for (int it = first; it < last; ++it) {
       const int prow = i * 16 + it * RB;  // first row of the batch inside the wave tile
       const bool ok = nok && prow + rr < rows_left;
       if (MODE == EPI_RES_F32) ld[i & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(tb.res, ok ? lane_r * 4u : OOB, (row0 + prow) * ldr * 4, kNT);
       else ld[i & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(tb.aux, ok ? lane_x * 2u : OOB, (row0 + prow) * ldx * 2, kNT);
     }
   };
-  issue_loads(0);
+  issue_loads(0, 0, T::batches);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(patch + frow * 512 + (((j * 4 + fchk) ^ (frow & 7)) << 4)) = acc[i][j];
-    if (i < 3) issue_loads(i + 1);
+    if (i < 3) issue_loads(i + 1, 0, kHalf);
 #pragma unroll
     for (int it = 0; it < T::batches; ++it) {
       const int pr = it * RB + rr;        // row inside the 16-row patch
@@ -566,9 +569,9 @@ __device__ __forceinline__ void epilogue_wave64x128_m(const Epilogue& e, const T
             x0[q] *= dgelu_fast((float)t[q]);
             x1[q] *= dgelu_fast((float)t[4 + q]);
           }
-          if (MODE == EPI_DGELU_CS && ok) {  // fused bias gradient of the Linear feeding the GELU (column sums of this output)
-            csum[0] += x0;
-            csum[1] += x1;
+          if (MODE == EPI_DGELU_CS) {  // fused bias gradient of the Linear feeding the GELU (column sums of this output)
+            cs0 += ok ? x0 : f32x4{0, 0, 0, 0};
+            cs1 += ok ? x1 : f32x4{0, 0, 0, 0};
           }
         }
         __builtin_amdgcn_raw_buffer_store_b128(pack(x0, x1), tb.c, vc, sc, kNT);
@@ -579,6 +582,7 @@ __device__ __forceinline__ void epilogue_wave64x128_m(const Epilogue& e, const T
         if (MODE == EPI_RES_F32) x += __builtin_bit_cast(f32x4, ld[i & 1][it]);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), tb.c, ok ? lane_c * 4u : OOB, (row0 + prow) * ldc * 4, kNT);
         HCT_STORE_GUARD();
+        if (i < 3 && it == kHalf - 1) issue_loads(i + 1, kHalf, T::batches);
       }
     }
   }
@@ -629,6 +633,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ntm = (M + 255) >> 8, ntn = (N + 255) >> 8;
   const int dbg = e.dbg;
+  float* const colsum_out = e.colsum_partial;  // by value: indexing through `e` made hipcc keep a copy of the struct in scratch
 
   // staging: 1 KiB piece = 16 rows x 64 B; wave w moves pieces 2w, 2w+1 of A and of B each stage
   uint32_t voa[2], vob[2];
@@ -706,19 +711,6 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
-  // The first three waits of a tile that follows another tile: the previous epilogue's loads/stores (kEpiOps per wave,
-  // all issued unconditionally, OOB-predicated) are YOUNGER than the prefetched stages 0..2, and vmcnt retires in order,
-  // so "stage s landed" = "all but (younger stages + kEpiOps) retired".  Waiting with the plain counts would hold the
-  // tile's first MFMAs until the whole store burst of the previous tile has drained to HBM.
-  constexpr int kEpiOps = MODE == EPI_GENERIC ? 0 : EpiTraits<MODE>::ops_per_tile;
-  auto land_after_epilogue = [&](int later_stages) {  // later_stages = 2 (stage 0) or 1 (stages 1, 2)
-    constexpr int c2 = (8 + kEpiOps) > 63 ? 63 : (8 + kEpiOps), c1 = (4 + kEpiOps) > 63 ? 63 : (4 + kEpiOps);
-    if (later_stages == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(c2) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(c1) : "memory");
-    __builtin_amdgcn_s_barrier();
-  };
-  bool after_epi = false;  // wave-uniform: this tile was prefetched under a previous tile's epilogue
-
   // De-phase the persistent workgroups: all tiles cost the same, so without this every CU reaches its epilogue at the same
   // moment and the chip alternates between an HBM write burst (matrix pipes idle, vmcnt is in-order so the next tile
   // cannot start until the stores drain) and a pure-MFMA phase.  Eight start phases spread the bursts over the main loops
@@ -744,9 +736,10 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
     // nk is even and >= 4 (host dispatch: K % 64 == 0, K >= 128): steady-state loop without conditionals + static tail.
-    // vmcnt(8) here also covers the previous tile's epilogue stores (older than the three prefetched stages).
-    const bool relax = after_epi && MODE != EPI_GENERIC && nk >= 6 && stagger != -7;
-    if (relax) land_after_epilogue(2); else land(2);
+    // The three prefetched stages are OLDER than the previous epilogue's loads and stores (vmcnt retires in issue order),
+    // so this vmcnt(8) also waits for all but the last 8 of those.  Counted waits that let the stores drain under the
+    // first MFMAs were tried and measured no gain: the epilogue is bound by store issue (~75 clk per wave-store), not drain.
+    land(2);
     HCT_STAMP(1);
     rd_a(0, a0);
     rd_b(0, 0, b_lo);
@@ -754,14 +747,14 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     for (; t + 4 < nk; t += 2) {
       rd_b(t, 1, b_hi);
       mma(0, a0, b_lo);
-      if (relax && t == 0) land_after_epilogue(1); else land(1);
+      land(1);
       stage(t + 3);
       rd_a(t + 1, a1);
       rd_b(t + 1, 0, b_lo);
       mma(1, a0, b_hi);
       rd_b(t + 1, 1, b_hi);
       mma(0, a1, b_lo);
-      if (relax && t == 0) land_after_epilogue(1); else land(1);
+      land(1);
       stage(t + 4);
       rd_a(t + 2, a0);
       rd_b(t + 2, 0, b_lo);
@@ -800,7 +793,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     TileBias bv = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
     if (MODE != EPI_GENERIC) {
       bv = tile_bias<MODE>(e, cn0, wn * 128, lane, N);
-      asm volatile("" : "+v"(bv.lo), "+v"(bv.hi));
+      if (EpiTraits<MODE>::wide) asm volatile("" : "+v"(bv.lo), "+v"(bv.hi));
+      else asm volatile("" : "+v"(bv.lo));
     }
     vb += gridDim.x;
     const bool more = vb < ntiles;
@@ -810,7 +804,6 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
       stage(1);
       stage(2);
     }
-    after_epi = true;
     if (MODE == EPI_GENERIC && dbg == 1) {  // timing experiment: no output traffic (keep the accumulators alive)
       float sacc = 0.f;
 #pragma unroll
@@ -844,21 +837,21 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
 #pragma unroll
         for (int i = 0; i < 4; ++i) epilogue_tile16x128(e, patch, lane, cm0 + wm * 64 + i * 16, cn0 + wn * 128, M, N, acc[i]);
       } else {
-        f32x4 cs[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-        epilogue_wave64x128_m<MODE>(e, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv, cs);
+        f32x4 cs0 = {0, 0, 0, 0}, cs1 = {0, 0, 0, 0};
+        epilogue_wave64x128_m<MODE>(e, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv, cs0, cs1);
         if (MODE == EPI_DGELU_CS) {  // lanes l, l+16, l+32, l+48 hold 4 different rows of the same 8 columns
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              cs[h][q] += __shfl_xor(cs[h][q], 16, 64);
-              cs[h][q] += __shfl_xor(cs[h][q], 32, 64);
-            }
+          for (int q = 0; q < 4; ++q) {
+            cs0[q] += __shfl_xor(cs0[q], 16, 64);
+            cs0[q] += __shfl_xor(cs0[q], 32, 64);
+            cs1[q] += __shfl_xor(cs1[q], 16, 64);
+            cs1[q] += __shfl_xor(cs1[q], 32, 64);
+          }
           const int n = cn0 + wn * 128 + (lane & 15) * 8;
           if (lane < 16 && n < N) {
-            float* dst = e.colsum_partial + ((int64_t)((cm0 >> 8) * 4 + wm)) * N + n;
-            Vec4<float>::store(dst, cs[0]);
-            Vec4<float>::store(dst + 4, cs[1]);
+            float* dst = colsum_out + ((int64_t)((cm0 >> 8) * 4 + wm)) * N + n;
+            Vec4<float>::store(dst, cs0);
+            Vec4<float>::store(dst + 4, cs1);
           }
         }
       }
@@ -1031,7 +1024,8 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_nt_w4_kernel(int M, int N, i
         for (int i = 0; i < 4; ++i) epilogue_tile16x128(e, patch, lane, m0 + wm * 64 + i * 16, n0, M, N, acc[i]);
       } else {
         TileBias bv = tile_bias<MODE>(e, n0, 0, lane, N);
-        epilogue_wave64x128_m<MODE>(e, tb, patch, lane, m0, n0, wm * 64, 0, M, N, acc, bv);
+        f32x4 cs0 = {0, 0, 0, 0}, cs1 = {0, 0, 0, 0};
+        epilogue_wave64x128_m<MODE>(e, tb, patch, lane, m0, n0, wm * 64, 0, M, N, acc, bv, cs0, cs1);
       }
     }
     __syncthreads();  // patches dead before the next tile's DMA overwrites the ring
@@ -1054,14 +1048,6 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
   const uint32_t OOB = 0xFFFFFFF0u;
 
   // staging: 1 KiB piece = 2 reduction rows x 512 B; wave w moves pieces 2w, 2w+1 of A and of B each stage
-  int srow[2], scol[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    srow[i] = (wave * 2 + i) * 2 + (lane >> 5);
-    const int slot = lane & 31;
-    const int f = (srow[i] & 3) | (((srow[i] >> 3) & 1) << 2);
-    scol[i] = ((((slot >> 1) ^ f) << 1) | (slot & 1)) * 8;
-  }
   uint32_t voa[2], vob[2];
   // The operand stream of this kernel is issued as INLINE-ASM LDS-DMA.  With the builtin, hipcc (ROCm 7.2) inserts
   // s_waitcnt vmcnt(0) between a stage's DMA issue and the ds_read_b64_tr_b16 fragment reads (it treats the transposed
@@ -1085,22 +1071,33 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
     const bf16* Bb = B + (int64_t)rbeg * ldb + n0;
     ra = make_srd(Ab, clamp_records(((int64_t)(rows - 1) * lda + (M - m0)) * 2));
     rb = make_srd(Bb, clamp_records(((int64_t)(rows - 1) * ldb + (N - n0)) * 2));
+    // lane offsets recomputed per tile from an opaque lane id (a dozen VALU): as tile-invariant values hipcc kept them in
+    // VGPRs across the main loop, spilled them, and reloaded them here one by one with s_waitcnt vmcnt(0)
+    int l = lane;
+    asm volatile("" : "+v"(l));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      voa[i] = (m0 + scol[i] < M) ? (uint32_t)((srow[i] * lda + scol[i]) * 2) : OOB;
-      vob[i] = (n0 + scol[i] < N) ? (uint32_t)((srow[i] * ldb + scol[i]) * 2) : OOB;
+      const int srow = (wave * 2 + i) * 2 + (l >> 5);
+      const int slot = l & 31;
+      const int f = (srow & 3) | (((srow >> 3) & 1) << 2);
+      const int scol = ((((slot >> 1) ^ f) << 1) | (slot & 1)) * 8;
+      voa[i] = (m0 + scol < M) ? (uint32_t)((srow * lda + scol) * 2) : OOB;
+      vob[i] = (n0 + scol < N) ? (uint32_t)((srow * ldb + scol) * 2) : OOB;
     }
   };
   auto stage = [&](int t) {
     const uint32_t base = lds0 + (t & 3) * 32768;
-    const uint32_t ka = (uint32_t)(t * 32 * lda * 2), kb = (uint32_t)(t * 32 * ldb * 2);
+    uint32_t ka = (uint32_t)(t * 32 * lda * 2), kb = (uint32_t)(t * 32 * ldb * 2);
+    // opaque per call: otherwise hipcc pre-adds the stage offsets of the three prefetch stages into 12 long-lived VGPRs,
+    // spills them and reloads each with s_waitcnt vmcnt(0) between the prefetch DMAs
+    asm volatile("" : "+s"(ka), "+s"(kb));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = wave * 2 + i;
       // NOTE: the reduction-row offset must stay in voffset here (rows past the split's end are zero-filled by the
       // descriptor's range check, which does not see soffset)
-      dma16(ra, __builtin_amdgcn_readfirstlane(base + c * 1024), voa[i] == OOB ? OOB : voa[i] + ka);
-      dma16(rb, __builtin_amdgcn_readfirstlane(base + 16384 + c * 1024), vob[i] == OOB ? OOB : vob[i] + kb);
+      dma16(ra, base + c * 1024, voa[i] == OOB ? OOB : voa[i] + ka);
+      dma16(rb, base + 16384 + c * 1024, vob[i] == OOB ? OOB : vob[i] + kb);
     }
   };
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
@@ -1234,7 +1231,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
       tb.c = tile_rsrc(eo.C, eo.ldc, 4, cm0, cn0, M, N);
       tb.res = tile_rsrc(nullptr, 0, 4, cm0, cn0, M, N);
       tb.aux = tb.res;
-      epilogue_wave64x128_m<EPI_PLAIN_F32>(eo, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv);
+      f32x4 cs0 = {0, 0, 0, 0}, cs1 = {0, 0, 0, 0};
+      epilogue_wave64x128_m<EPI_PLAIN_F32>(eo, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv, cs0, cs1);
     }
     if (!more) break;
   }
@@ -1529,7 +1527,7 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
       // one start phase = 1/8 of a tile's main loop (nk stages x ~1000 cycles; s_sleep(32) = 2048 cycles); only when each
       // CU runs several tiles (otherwise the delay is pure loss)
       int stagger = 0;
-      if (g_stagger >= 0 || g_stagger == -7) stagger = g_stagger;  // -7: no stagger, no relaxed waits (diagnostics)
+      if (g_stagger >= 0) stagger = g_stagger;
       else if (tiles256 >= 3 * (int)grid.x) stagger = std::max(1, (a->K / 32) / 16);
 #define HCT_NT256(MODE_)                                                                                              \
   hipLaunchKernelGGL(gemm_bf16_nt256_kernel<MODE_>, grid, dim3(512), 0, s, a->M, a->N, a->K, (const bf16*)a->A, a->lda, \

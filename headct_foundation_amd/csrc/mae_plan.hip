@@ -265,10 +265,11 @@ int block_backward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const fl
   void* small = ws + p->s_small;
   // MLP branch
   RC(linear_wgrad(p, dhs, ws + ba.g, M, d, m, bp.fc2_w, -1, s));
-  // d(pre-GELU) = (dh . W2) * gelu'(u).  (hct_gemm can fuse the linear1 bias gradient = column sums of this output into
-  // the epilogue -- colsum_out -- but that instance spills in its epilogue and measured slower than a separate pass.)
-  RC(linear_dgrad(p, dhs, M, d, bp.fc2_w, m, dbig, HCT_ACT_DGELU, ws + ba.u, s));
-  RC(linear_wgrad(p, dbig, ws + ba.x2, M, m, d, bp.fc1_w, bp.fc1_b, s));
+  // d(pre-GELU) = (dh . W2) * gelu'(u); the linear1 bias gradient = column sums of this output rides in the same
+  // epilogue (colsum_out: per-row-tile partials + a fixed-order fold; hct_gemm falls back to a separate pass over the
+  // output where the fused instance does not apply)
+  RC(linear_dgrad(p, dhs, M, d, bp.fc2_w, m, dbig, HCT_ACT_DGELU, ws + ba.u, s, p->gf(bp.fc1_b)));
+  RC(linear_wgrad(p, dbig, ws + ba.x2, M, m, d, bp.fc1_w, -1, s));
   RC(linear_dgrad(p, dbig, M, m, bp.fc1_w, d, dx, HCT_ACT_NONE, nullptr, s));
   RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + ba.h_mid), (const float*)(ws + ba.mean2), (const float*)(ws + ba.rstd2),
                        p->pf(bp.ln2_w), dh, M, d, dh, dhs, p->dt, p->gf(bp.ln2_w), p->gf(bp.ln2_b), p->gf(bp.proj_b), small,

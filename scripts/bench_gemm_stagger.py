@@ -1,14 +1,20 @@
-import os, sys
+"""Start-phase stagger sweep of the persistent 256x256 NT kernel on the decoder-block shapes (real epilogues)."""
+import os, sys, io, contextlib
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from bench_gemm import run, lib
-Md, Me = 256 * 217, 256 * 55
-for (M, N, K) in [(Md, 2304, 768), (Md, 768, 768), (Md, 3072, 768), (Md, 4096, 768), (Me, 2304, 768), (Me, 3072, 768), (Md, 768, 3072)]:
-    out = []
-    for st in (0, 4, 8, 12, 16, 24):
+with contextlib.redirect_stdout(io.StringIO()):
+    import bench_gemm_model as g
+lib = g.lib
+Md = 256 * 217
+shapes = [("qkv fwd", dict(M=Md, N=2304, K=768)), ("proj fwd", dict(M=Md, N=768, K=768, out_f32=True, bias=True, residual=True)),
+          ("fc1 fwd", dict(M=Md, N=3072, K=768, bias=True, act=1)), ("fc2 fwd", dict(M=Md, N=768, K=3072, out_f32=True, bias=True, residual=True)),
+          ("fc2 dgrad", dict(M=Md, N=3072, K=768, act=2)), ("fc1 dgrad", dict(M=Md, N=768, K=3072)), ("qkv dgrad", dict(M=Md, N=768, K=2304))]
+lib.hct_debug_set_gemm_variant(256)
+for name, kw in shapes:
+    row = []
+    for st in (0, 1, 2, 3, 4, 6, 8, -1):
         lib.hct_debug_set_gemm_stagger(st)
-        tf, us = run("nt", M, N, K, 4)
-        out.append(f"st={st}: {tf:6.1f}TF")
-    lib.hct_debug_set_gemm_stagger(-1)
-    tf, us = run("nt", M, N, K, 4)
-    t2, u2 = run("nt", M, N, K, 256)
-    print(f"M={M} N={N} K={K}: w4 " + " | ".join(out) + f" | auto: {tf:6.1f}TF {us:6.1f}us || 256^2: {t2:6.1f}TF {u2:6.1f}us")
+        with contextlib.redirect_stdout(io.StringIO()):
+            us = g.call(name, kw["M"], kw["N"], kw["K"], **{k: v for k, v in kw.items() if k not in "MNK"})
+        row.append(f"{st}:{us:6.1f}")
+    print(f"{name:10s} " + "  ".join(row))
+lib.hct_debug_set_gemm_stagger(-1)

@@ -68,7 +68,7 @@ def call(name, M, N, K, out_f32=False, bias=False, residual=False, act=0, stagge
 
 Md = 256 * 217
 which = [a for a in sys.argv[1:] if not a.lstrip("-").isdigit()] or ["qkv", "fc1", "dgelu", "proj"]
-for stg in ([int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()] or (-1, 0, -7)):
+for stg in ([int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()] or (-1, 0)):
     if "qkv" in which: call("qkv fwd (plain bf16)", Md, 2304, 768, stagger=stg)
     if "fc1" in which: call("fc1 fwd (GELU, aux, bias)", Md, 3072, 768, bias=True, act=1, stagger=stg)
     if "dgelu" in which: call("fc2 dgrad (x gelu')", Md, 3072, 768, act=2, stagger=stg)
