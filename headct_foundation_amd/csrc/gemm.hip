@@ -16,7 +16,8 @@
 
 namespace hct {
 
-static int g_w4_auto = 0;   // auto-dispatch of the 2-WG/CU variant (enabled once measured)
+static int g_w4_auto = 0;   // auto-dispatch of the 2-WG/CU variant: faster in isolation on the decoder's GELU / +residual
+                            // GEMMs (362 vs 395 us, 126 vs 142 us) but 1 % slower inside the step -> off
 static int g_store_policy = 0;  // epilogue store cache policy experiment: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1
 static int g_stagger = -1;  // -1 auto, >= 0 forced (testing)
 static int g_nt_variant = 0;  // 0 auto, 128 / 256 forced (testing); +1000*k = timing experiments
@@ -1502,7 +1503,12 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
     if (big) {
       const int mode = epilogue_mode(a);
       // two-workgroups-per-CU variant for epilogue-dominated shapes (short K, wide output)
-      const bool w4 = (g_nt_variant % 1000 == 4) || (g_nt_variant == 0 && g_w4_auto && a->K <= 1024);
+      // measured crossover (scripts/bench_gemm_model.py, B=256): with two workgroups per CU one drains its tile while the
+      // other computes, which pays for the 1.5x operand traffic only where the epilogue is heavy (GELU: two outputs;
+      // +residual: fp32 read + write), K is short and there are several tiles per CU
+      const bool w4_shape = a->K <= 1024 && ((mode == EPI_GELU_BF16 && tiles256 >= 4 * num_cus()) ||
+                                             (mode == EPI_RES_F32 && tiles256 >= 2 * num_cus()));
+      const bool w4 = (g_nt_variant % 1000 == 4) || (g_nt_variant == 0 && g_w4_auto && w4_shape);
       if (w4) {
         const int tiles = ((a->M + 255) / 256) * ((a->N + 127) / 128);
         const dim3 g4(std::min(tiles, 2 * num_cus()));
