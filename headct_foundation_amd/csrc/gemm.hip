@@ -676,8 +676,12 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
       // the stage's K offset rides in the scalar soffset operand: the lane offsets stay tile- and stage-invariant (no
       // per-stage VALU, nothing for the compiler to pre-compute and spill); rows past M are still dropped by the
       // descriptor's range check on voffset
+#ifdef HCT_TIMING_NO_DMA  // diagnostic build: main loop without its operand stream (outputs are garbage)
+      asm volatile("" ::"s"(base + c * 1024), "v"(voa[i]), "v"(vob[i]), "s"(kb), "s"(ra), "s"(rb));
+#else
       dma16s(ra, base + c * 1024, voa[i], kb);
       dma16s(rb, base + 16384 + c * 1024, vob[i], kb);
+#endif
     }
   };
   // Software pipeline at half-stage granularity (16 live fragments: 4 A + 4 A' + 4 B-low + 4 B-high):

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from headct_foundation_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libheadct_hip_stamps.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"libheadct_hip_{os.environ.get('HCT_STAMP_LIB', 'stamps')}.so")
 from headct_foundation_amd._lib import HCT_BF16, HCT_F32, GemmArgs
 lib = _lib.load(); dev = torch.device("cuda"); st = torch.cuda.current_stream().cuda_stream
 lib.hct_debug_set_stamp_buffer.restype = C.c_int

@@ -40,3 +40,39 @@ for (M, N, K) in [(165, 768, 768), (512, 512, 256), (2048, 768, 768), (2048, 307
             del o
 for k, v in tot.items():
     print(sys.argv[1:] or "main", k, "bad calls", v[0], "/20, bad elements", v[1], "of which sentinel (store never landed)", v[2])
+
+# ---- run-to-run determinism + outlier check of the other MFMA kernels (wgrad TN GEMM, attention forward / backward) ----
+from test_kernels_gpu import _attn_ref, _dt, _st
+
+
+def outliers(x, ref, tol):
+    return int(((x.float() - ref).abs() > tol + tol * ref.abs()).sum())
+
+
+for (R, M, N) in [(55552, 768, 768), (14080, 2304, 768), (8192, 768, 3072)]:
+    A = _rand((R, M), cuda, torch.bfloat16, 5); B = _rand((R, N), cuda, torch.bfloat16, 6)
+    ref = A.float().t() @ B.float()
+    first, nd, no = None, 0, 0
+    for rep in range(10):
+        o = gemm(lib, A, B, 1, 0, M, N, R)
+        no += outliers(o, ref, 2e-3 * R ** 0.5)
+        if first is None: first = o.clone()
+        nd += int((o != first).sum())
+    print("tn wgrad", (R, M, N), "outliers", no, "elements differing between repeats", nd)
+
+for (Bb, Nt, H, dh) in [(64, 217, 16, 48), (64, 55, 12, 64)]:
+    qkv = _rand((Bb, Nt, 3 * H * dh), cuda, torch.bfloat16, 11); d_o = _rand((Bb, Nt, H * dh), cuda, torch.bfloat16, 12)
+    qr = qkv.float().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(qr, Bb, Nt, H, dh)
+    (o_ref * d_o.float()).sum().backward()
+    first, nd, no = None, 0, 0
+    for rep in range(10):
+        o = torch.empty(Bb, Nt, H * dh, dtype=torch.bfloat16, device=cuda); lse = torch.empty(Bb, H, Nt, dtype=torch.float32, device=cuda)
+        _lib.check(lib.hct_attention_fwd(qkv.data_ptr(), Bb, Nt, H, dh, _dt(qkv), o.data_ptr(), lse.data_ptr(), _st()), "fwd")
+        dqkv = torch.full_like(qkv, float("nan"))
+        _lib.check(lib.hct_attention_bwd(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), Bb, Nt, H, dh, _dt(qkv), dqkv.data_ptr(), _st()), "bwd")
+        no += outliers(o, o_ref.detach(), 0.03) + outliers(dqkv, qr.grad, 0.06)
+        cur = torch.cat([o.flatten().float(), dqkv.flatten().float()])
+        if first is None: first = cur.clone()
+        nd += int((cur != first).sum())
+    print("attention fwd+bwd", (Bb, Nt, H, dh), "outliers", no, "elements differing between repeats", nd)
