@@ -85,7 +85,7 @@ def cpu_baseline(seconds_budget: float = 25.0):
     x, noise = O.make_volume(cfg, B, 42), O.make_noise(cfg, B, 42)
     times = []
     t_start = time.time()
-    for i in range(8):
+    for i in range(16):  # ~14 s of CPU work at 0.87 s/step on the GPU box, cut off by seconds_budget on slower hosts
         t0 = time.time()
         O.train_step(cfg, st, x, noise, **hp)
         times.append(time.time() - t0)
