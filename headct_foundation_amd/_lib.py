@@ -73,6 +73,7 @@ _PROTOS = {
                                          c_void_p, c_size_t, c_void_p]),
     "hct_masked_mse": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hct_unpatchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "hct_pos_embed_interp3d": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "hct_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
     "hct_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "hct_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),

@@ -521,6 +521,47 @@ static int launch_ln_bwd(const void* dy, const float* x, const float* mean, cons
   return 0;
 }
 
+// trilinear resize of the position table (pos_embed.py:102-153): one thread per (output token, 4 channels); source index
+// arithmetic in fp32 exactly as ATen's area_pixel_compute_source_index (align_corners = false, negative clamped to 0)
+namespace hct {
+__global__ void pos_embed_interp3d_kernel(const float* __restrict__ src, int gs, float* __restrict__ dst, int gd, int D, int extra) {
+  const int d4 = D >> 2;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t ntok = (int64_t)extra + (int64_t)gd * gd * gd;
+  if (gid >= ntok * d4) return;
+  const int tok = (int)(gid / d4), c = (int)(gid - (int64_t)tok * d4) * 4;
+  if (tok < extra) {
+    Vec4<float>::store(dst + (int64_t)tok * D + c, Vec4<float>::load(src + (int64_t)tok * D + c));
+    return;
+  }
+  const int t = tok - extra;
+  const int oz = t % gd, oy = (t / gd) % gd, ox = t / (gd * gd);
+  const float scale = (float)gs / (float)gd;
+  int i0[3], i1[3];
+  float w1[3];
+  const int o[3] = {ox, oy, oz};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float cs = fmaxf(0.f, ((float)o[a] + 0.5f) * scale - 0.5f);
+    i0[a] = (int)cs;
+    i1[a] = min(i0[a] + 1, gs - 1);
+    w1[a] = cs - (float)i0[a];
+  }
+  f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float w = (a ? w1[0] : 1.f - w1[0]) * (b ? w1[1] : 1.f - w1[1]) * (e ? w1[2] : 1.f - w1[2]);
+        const int64_t row = extra + ((int64_t)(a ? i1[0] : i0[0]) * gs + (b ? i1[1] : i0[1])) * gs + (e ? i1[2] : i0[2]);
+        acc += w * Vec4<float>::load(src + row * D + c);
+      }
+  Vec4<float>::store(dst + (int64_t)tok * D + c, acc);
+}
+}  // namespace hct
+
 extern "C" {
 
 const char* hct_last_error_string(void) { return g_err; }
@@ -744,4 +785,13 @@ int hct_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
   return 0;
 }
 
+
+int hct_pos_embed_interp3d(const float* src, int g_src, float* dst, int g_dst, int D, int extra, void* stream) {
+  HCT_REQUIRE(src && dst && g_src > 0 && g_dst > 0 && D > 0 && D % 4 == 0 && extra >= 0, "hct_pos_embed_interp3d: bad arguments (D must be a multiple of 4)");
+  const int64_t n = ((int64_t)extra + (int64_t)g_dst * g_dst * g_dst) * (D / 4);
+  hipLaunchKernelGGL(hct::pos_embed_interp3d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, g_src, dst,
+                     g_dst, D, extra);
+  HCT_CHECK_LAUNCH("hct_pos_embed_interp3d");
+  return 0;
+}
 }  // extern "C"

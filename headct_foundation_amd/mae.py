@@ -196,6 +196,7 @@ class MaskedAutoencoderViT(nn.Module):
         self.decoder_cls_token = nn.Parameter(torch.zeros(1, 1, Dd))
         self.decoder_pos_embed = nn.Parameter(torch.zeros(1, num_patches, Dd), requires_grad=False)
         self.patch_embedding = _Holder()
+        self.patch_embedding.n_patches = num_patches  # attribute interpolate_pos_embed reads (patch_embedding.py:96)
         if pos_embed != "none":
             self.patch_embedding.position_embeddings = nn.Parameter(torch.zeros(1, num_patches, D))
         else:

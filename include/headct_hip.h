@@ -161,6 +161,11 @@ int hct_masked_mse(const void* pred, int pred_dtype, const float* x, const float
 int hct_unpatchify(const void* pred, int pred_dtype, int has_cls_row, int B, int C, int S, int P, float* vol,
                    void* stream);
 
+/* Resume at another resolution: trilinear resize (align_corners = false) of the learnable position table
+ * src [extra + g_src^3, D] -> dst [extra + g_dst^3, D], the `extra` leading (class) rows copied unchanged.
+ * Replaces interpolate_pos_embed's 3-D branch, src/utils/pos_embed.py:102-153 (called at main_pretrain_mae.py:132). */
+int hct_pos_embed_interp3d(const float* src, int g_src, float* dst, int g_dst, int D, int extra, void* stream);
+
 /* Column sum of a [rows, cols] matrix -> fp32 [cols] (bias gradients). workspace >= hct_colsum_workspace_bytes. */
 size_t hct_colsum_workspace_bytes(int rows, int cols);
 int hct_colsum(const void* x, int dtype, int rows, int cols, int64_t ld, float* out, void* workspace,

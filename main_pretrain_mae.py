@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from config import get_config
 from engine_pretrain_mae import tester, trainer
-from headct_foundation_amd import MaskedAutoencoderViT
+from headct_foundation_amd import MaskedAutoencoderViT, interpolate_pos_embed
 from headct_foundation_amd.data import get_pretrain_dataloaders
 from headct_foundation_amd.ddp import DistributedDataParallel
 from headct_foundation_amd.lr_sched import get_lr_scheduler
@@ -89,10 +89,14 @@ def main(config, wandb_run, logger):
         # tensors only (weights_only=True): reference checkpoints hold plain tensors / python scalars
         loaded_state_dict = torch.load(config.MODEL.PRETRAINED, map_location=torch.device('cpu'), weights_only=True)
         new_sd = {k.replace("module.", ""): v for k, v in loaded_state_dict['state_dict'].items()}
+        # resuming at another resolution: resize the learnable position table (main_pretrain_mae.py:132)
+        interpolate_pos_embed(model, new_sd)
         own = model.state_dict()
-        for k in ("patch_embedding.position_embeddings", "decoder_pos_embed"):
-            if k in new_sd and k in own and new_sd[k].shape != own[k].shape:
-                raise SystemExit(f"{k}: resuming at a different resolution (pos-embed interpolation) is out of scope")
+        if "decoder_pos_embed" in new_sd and new_sd["decoder_pos_embed"].shape != own["decoder_pos_embed"].shape:
+            # the reference stops here as well: interpolate_pos_embed only treats the encoder table, and load_state_dict
+            # raises on a size mismatch even with strict=False
+            raise SystemExit(f"size mismatch for decoder_pos_embed: checkpoint {tuple(new_sd['decoder_pos_embed'].shape)} vs "
+                             f"model {tuple(own['decoder_pos_embed'].shape)}")
         msg = model.load_state_dict(new_sd, strict=False)
         logger.info(f"Load Pretrained Model: {msg} for Architecture: {config.MODEL.NAME}")
 

@@ -175,6 +175,34 @@ def build_sincos_position_embedding_3d(grid: int, embed_dim: int, temperature: f
                       torch.sin(od), torch.cos(od)], dim=1)[None]
 
 
+def interpolate_pos_embed_3d(pos: torch.Tensor, new_grid: int, num_extra_tokens: int = 0) -> torch.Tensor:
+    """Trilinear resize of a learnable position table [1, extra + g^3, D] to [1, extra + new_grid^3, D]
+    (src/utils/pos_embed.py:102-153, 3-D branch: F.interpolate(mode='trilinear', align_corners=False) on the
+    [1, D, g, g, g] view; extra (class) tokens are kept).  Written out with explicit index arithmetic: source coordinate
+    max(0, (dst + 0.5) * g/new - 0.5) in fp32, neighbours i0 = floor, i1 = min(i0 + 1, g - 1), weight = coordinate - i0;
+    the three axes are applied innermost (depth) first, as ATen's upsample_trilinear3d accumulates them."""
+    extra, tok = pos[:, :num_extra_tokens], pos[:, num_extra_tokens:]
+    D = tok.shape[-1]
+    g = int(round(tok.shape[1] ** (1.0 / 3.0)))
+    assert g ** 3 == tok.shape[1], "position table is not a cubic grid"
+    if g == new_grid:
+        return pos.clone()
+    src = tok.reshape(g, g, g, D).to(torch.float32)
+    scale = np.float32(g) / np.float32(new_grid)
+    c = np.maximum(np.float32(0), (np.arange(new_grid, dtype=np.float32) + np.float32(0.5)) * scale - np.float32(0.5)).astype(np.float32)
+    i0 = np.floor(c).astype(np.int64)
+    i1 = np.minimum(i0 + 1, g - 1)
+    w1 = torch.from_numpy((c - i0.astype(np.float32)).astype(np.float32))
+    w0 = 1.0 - w1
+    i0t, i1t = torch.from_numpy(i0), torch.from_numpy(i1)
+    out = torch.zeros(new_grid, new_grid, new_grid, D, dtype=torch.float32)
+    for a, (ia, wa) in enumerate(((i0t, w0), (i1t, w1))):
+        for b, (ib, wb) in enumerate(((i0t, w0), (i1t, w1))):
+            for c_, (ic, wc) in enumerate(((i0t, w0), (i1t, w1))):
+                out += (wa[:, None, None, None] * wb[None, :, None, None] * wc[None, None, :, None]) * src[ia][:, ib][:, :, ic]
+    return torch.cat([extra, out.reshape(1, new_grid ** 3, D)], dim=1)
+
+
 def hash_uniform(n: int, seed: int) -> np.ndarray:
     """Portable deterministic U[-1,1) stream (integer hash; independent of any RNG library)."""
     i = np.arange(n, dtype=np.uint64)

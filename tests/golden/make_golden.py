@@ -282,6 +282,25 @@ def sincos_fixture():
         json.dump(out, f)
 
 
+def pos_interp_fixture():
+    """interpolate_pos_embed (pos_embed.py:102-153) on a learnable table, up- and down-sampling; full outputs (small)."""
+    from src.utils.pos_embed import interpolate_pos_embed
+    out = {}
+    for g_old, g_new, d, seed in ((4, 6, 12, 3), (6, 4, 12, 4), (2, 5, 6, 5), (6, 8, 24, 6)):
+        table = torch.from_numpy(O.hash_uniform(g_old ** 3 * d, seed).reshape(1, g_old ** 3, d).astype(np.float32))
+        fake = types.SimpleNamespace(patch_embedding=types.SimpleNamespace(
+            n_patches=g_new ** 3, position_embeddings=torch.zeros(1, g_new ** 3, d)))
+        ckpt = {"patch_embedding.position_embeddings": table.clone()}
+        interpolate_pos_embed(fake, ckpt, spatial_dims=3)
+        ref = ckpt["patch_embedding.position_embeddings"]
+        mine = O.interpolate_pos_embed_3d(table, g_new, 0)
+        err = float((ref - mine).abs().max())
+        assert ref.shape == mine.shape and err < 2e-6, (g_old, g_new, err)
+        out[f"{g_old}_{g_new}_{d}_{seed}"] = dict(max_abs_dev_oracle=err, ref=[float(v) for v in ref.flatten().tolist()])
+    with open(os.path.join(HERE, "pos_interp.json"), "w") as f:
+        json.dump(out, f)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted: fixtures can only be regenerated in the build container"
     sys.dont_write_bytecode = True
@@ -291,6 +310,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     sincos_fixture()
     lr_schedule_fixture()
+    pos_interp_fixture()
     run_case("micro", 2, 0, full=True)
     run_case("yaml_cut", 2, 1, full=False)
     run_case("tiny", 2, 0, full=False)

@@ -278,3 +278,34 @@ def test_gemm_dgelu_fused_colsum(lib, cuda):
         assert rel_err(Cm, want) < 4e-3
         # the fused sums are taken before bf16 rounding, the fallback after: both within bf16 noise of the fp32 sum
         assert rel_err(cs, want.sum(0)) < 3e-3, (M, N, K)
+
+
+def test_pos_embed_interp3d_vs_oracle_and_reference_fixture(lib, cuda):
+    """hct_pos_embed_interp3d and the host mirror interpolate_pos_embed vs the oracle and the reference-generated fixture."""
+    import json, os, types
+    import numpy as np
+    from oracle import mae_oracle as O
+    from headct_foundation_amd.pos_embed import interpolate_pos_embed
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pos_interp.json")))
+    for key, rec in fx.items():
+        g_old, g_new, d, seed = (int(v) for v in key.split("_"))
+        if d % 4:
+            continue  # the kernel moves 4 channels per thread (embed dims of the path are multiples of 4)
+        table = torch.from_numpy(O.hash_uniform(g_old ** 3 * d, seed).reshape(1, g_old ** 3, d).astype(np.float32))
+        ref = torch.tensor(rec["ref"], dtype=torch.float32).reshape(1, g_new ** 3, d)
+        fake = types.SimpleNamespace(patch_embedding=types.SimpleNamespace(
+            n_patches=g_new ** 3, position_embeddings=torch.zeros(1, g_new ** 3, d, device=cuda)))
+        ckpt = {"patch_embedding.position_embeddings": table.clone()}
+        interpolate_pos_embed(fake, ckpt)
+        out = ckpt["patch_embedding.position_embeddings"]
+        assert out.device.type == "cpu" and out.shape == ref.shape
+        assert float((out - ref).abs().max()) < 2e-6, key
+        assert float((out - O.interpolate_pos_embed_3d(table, g_new, 0)).abs().max()) < 2e-6, key
+    # class row kept, ViT-B-sized table (6^3 -> 8^3, D = 768) against the oracle
+    t = torch.from_numpy(O.hash_uniform((1 + 216) * 768, 9).reshape(1, 217, 768).astype(np.float32))
+    src = t.to(cuda)
+    dst = torch.empty(1, 1 + 512, 768, device=cuda)
+    _lib.check(lib.hct_pos_embed_interp3d(src.data_ptr(), 6, dst.data_ptr(), 8, 768, 1, _st()), "interp")
+    torch.cuda.synchronize()
+    want = O.interpolate_pos_embed_3d(t, 8, 1)
+    assert torch.equal(dst[:, :1].cpu(), t[:, :1]) and float((dst.cpu() - want).abs().max()) < 2e-6

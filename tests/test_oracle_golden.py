@@ -89,3 +89,25 @@ def test_algorithmic_flops_match_survey():
     f = O.algorithmic_flops_per_volume(O.CONFIGS["vitb"])
     assert abs(f["train"] / 1e9 - 110.85) < 0.01  # SURVEY 8d / BASELINE.md
     assert abs(O.algorithmic_flops_per_volume(O.CONFIGS["tiny"])["train"] / 1e9 - 1.295) < 0.001
+
+
+def test_pos_embed_interpolation_against_reference_fixture():
+    """oracle.interpolate_pos_embed_3d vs outputs of the reference's interpolate_pos_embed (pos_embed.py:102-153)."""
+    import json, os
+    import numpy as np
+    import torch
+    from oracle import mae_oracle as O
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pos_interp.json")))
+    assert len(fx) >= 4
+    for key, rec in fx.items():
+        g_old, g_new, d, seed = (int(v) for v in key.split("_"))
+        table = torch.from_numpy(O.hash_uniform(g_old ** 3 * d, seed).reshape(1, g_old ** 3, d).astype(np.float32))
+        out = O.interpolate_pos_embed_3d(table, g_new, 0)
+        ref = torch.tensor(rec["ref"], dtype=torch.float32).reshape(1, g_new ** 3, d)
+        assert out.shape == ref.shape
+        assert float((out - ref).abs().max()) < 2e-6, key  # fp32 trilinear weights; summation order differs from ATen's
+    # extra (class) tokens are carried over unchanged, equal grids are a no-op
+    t = torch.arange(2 * (8 + 1) * 4, dtype=torch.float32).reshape(1, 2 * 9, 4)[:, :9]
+    o = O.interpolate_pos_embed_3d(t, 3, 1)
+    assert o.shape == (1, 28, 4) and torch.equal(o[:, :1], t[:, :1])
+    assert torch.equal(O.interpolate_pos_embed_3d(t, 2, 1), t)
