@@ -126,11 +126,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    # rehearsal of the N>1 path on a one-GPU box: HCT_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo (the
+    # driver's runs use one rank per GPU over RCCL, the default)
+    rehearsal = os.environ.get("HCT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     lib = _lib.load()
     B, G = args.batch, world

@@ -1,0 +1,93 @@
+"""GPU, world_size 2 on ONE card (gloo backend moving device tensors): the real HIP model under the data-parallel wrapper.
+
+The 8-GPU RCCL run is the driver's; here the same code path (constructor broadcast, backward seeded with dLoss/world,
+staged bucket all-reduce of the flat gradient buffer launched from the native backward's stage callbacks, CU reserve,
+optimizer step on the wrapped module) runs with two ranks sharing cuda:0 and is checked against a single-process step over
+the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, dtype, cap_mb, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import mae_oracle as O
+        from tests.util import build_hip_model, grads_by_name, rel_err
+        from headct_foundation_amd.ddp import DistributedDataParallel
+        from headct_foundation_amd.optim import HipAdamW, clip_gradients
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        cfg = O.CONFIGS["tiny"]
+        B = 2
+        params = O.make_params(cfg, 0)
+        # rank 1 starts from perturbed weights: the constructor must broadcast rank 0's
+        start = {k: (v if rank == 0 else v + 0.01) for k, v in params.items()}
+        model = build_hip_model(cfg, start, dev, dtype).train()
+        ddp = DistributedDataParallel(model, device_ids=[dev], bucket_cap_mb=cap_mb)
+        xs = [O.make_volume(cfg, B, 20 + r).to(dev) for r in range(world)]
+        ns = [O.make_noise(cfg, B, 20 + r).to(dev) for r in range(world)]
+        opt = HipAdamW(ddp, lr=1e-3, weight_decay=5e-3, betas=(0.9, 0.95))
+        opt.zero_grad()
+        loss, _, _ = ddp(xs[rank], noise=ns[rank])
+        loss.backward()
+        torch.cuda.synchronize()
+        g = grads_by_name(model)
+        nb = len(ddp.launched)
+        # reference: one process, both batches at once (every sample masks the same number of patches, so the loss over
+        # 2B samples is the mean of the ranks' losses and its gradient the mean of the ranks' gradients)
+        single = build_hip_model(cfg, params, dev, dtype).train()
+        ls, _, _ = single(torch.cat(xs), noise=torch.cat(ns))
+        ls.backward()
+        torch.cuda.synchronize()
+        gs = grads_by_name(single)
+        tol = 2e-4 if dtype == "fp32" else 2e-2
+        worst = max((rel_err(g[k], gs[k]), k) for k in g if not k.endswith("qkv.bias"))
+        assert worst[0] < tol, worst
+        clip_gradients(ddp, 3.0)
+        opt.step()
+        torch.cuda.synchronize()
+        flat = model._flat.detach().clone()
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], t) for t in gathered), "replicas diverged after one step"
+        assert all(k.startswith("module.") for k in ddp.state_dict())
+        if rank == 0:
+            out.put((nb, float(worst[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype,cap_mb", [("fp32", 1e-9), ("bf16", 8.0)])
+def test_two_ranks_one_card(cuda, dtype, cap_mb):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dtype, cap_mb, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    nb, worst = out.get(timeout=5)
+    assert nb >= 1
+    if cap_mb < 1e-6:
+        assert nb > 3  # one bucket per backward stage with a zero cap
