@@ -521,6 +521,37 @@ static int launch_ln_bwd(const void* dy, const float* x, const float* mean, cons
   return 0;
 }
 
+// input transforms (transforms.py:193-228): cast + per-sample axis flips + intensity shift; one thread per 4 voxels of the
+// innermost axis (a flipped innermost axis is read as a reversed group of 4)
+namespace hct {
+template <typename TIn>
+__global__ void augment_volume_kernel(const TIn* __restrict__ in, float* __restrict__ out, int C, int S, const unsigned char* __restrict__ flip,
+                                      const float* __restrict__ shift, int64_t total4) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total4) return;
+  const int s4 = S >> 2;
+  const int k4 = (int)(gid % s4);
+  int64_t r = gid / s4;
+  const int j = (int)(r % S); r /= S;
+  const int i = (int)(r % S); r /= S;  // r = b * C + c
+  const int b = (int)(r / C);
+  const unsigned f = flip ? flip[b] : 0u;
+  const float sh = shift ? shift[b] : 0.f;
+  const int si = (f & 1u) ? S - 1 - i : i, sj = (f & 2u) ? S - 1 - j : j;
+  const TIn* row = in + ((r * S + si) * S + sj) * S;
+  f32x4 v;
+  if (f & 4u) {
+    const int k0 = S - 4 - k4 * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (float)row[k0 + 3 - q] + sh;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (float)row[k4 * 4 + q] + sh;
+  }
+  Vec4<float>::store(out + ((r * S + i) * S + j) * S + k4 * 4, v);
+}
+}  // namespace hct
+
 // trilinear resize of the position table (pos_embed.py:102-153): one thread per (output token, 4 channels); source index
 // arithmetic in fp32 exactly as ATen's area_pixel_compute_source_index (align_corners = false, negative clamped to 0)
 namespace hct {
@@ -792,6 +823,20 @@ int hct_pos_embed_interp3d(const float* src, int g_src, float* dst, int g_dst, i
   hipLaunchKernelGGL(hct::pos_embed_interp3d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, g_src, dst,
                      g_dst, D, extra);
   HCT_CHECK_LAUNCH("hct_pos_embed_interp3d");
+  return 0;
+}
+
+int hct_augment_volume(const void* in, int in_dtype, float* out, int B, int C, int S, const unsigned char* flip,
+                       const float* shift, void* stream) {
+  HCT_REQUIRE(in && out && B > 0 && C > 0 && S > 0 && S % 4 == 0 && (const void*)out != in, "hct_augment_volume: bad arguments (S must be a multiple of 4)");
+  HCT_REQUIRE(in_dtype == HCT_F32 || in_dtype == HCT_BF16 || in_dtype == HCT_F16, "hct_augment_volume: unsupported input dtype %d", in_dtype);
+  const int64_t n4 = (int64_t)B * C * S * S * (S / 4);
+  const dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (in_dtype == HCT_F32) hipLaunchKernelGGL(hct::augment_volume_kernel<float>, grid, block, 0, s, (const float*)in, out, C, S, flip, shift, n4);
+  else if (in_dtype == HCT_BF16) hipLaunchKernelGGL(hct::augment_volume_kernel<hct::bf16>, grid, block, 0, s, (const hct::bf16*)in, out, C, S, flip, shift, n4);
+  else hipLaunchKernelGGL(hct::augment_volume_kernel<_Float16>, grid, block, 0, s, (const _Float16*)in, out, C, S, flip, shift, n4);
+  HCT_CHECK_LAUNCH("hct_augment_volume");
   return 0;
 }
 }  // extern "C"

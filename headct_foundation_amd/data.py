@@ -1,10 +1,46 @@
-"""Input side of the MAE engine.  The reference's MONAI pipeline (src/data/*.py: NIfTI -> RAS -> 1 mm -> HU window ->
-resize -> fp16 persistent cache) is outside this round's scope and MONAI is absent from the image;
-the engine is fed synthetic volumes with the value range of windowed CT, U[0,1) (transforms.py:120-128), generated
-per rank with seed SEED + rank like the reference seeds its ranks (main_pretrain_mae.py:213)."""
+"""Input side of the MAE engine.  The reference's MONAI loading pipeline (src/data/*.py: NIfTI -> RAS -> 1 mm -> HU
+window -> resize -> fp16 persistent cache) needs MONAI, which is absent from the image; the engine is fed synthetic volumes
+with the value range of windowed CT, U[0,1) (transforms.py:120-128), generated per rank with seed SEED + rank like the
+reference seeds its ranks (main_pretrain_mae.py:213).  What IS built of the input path is its per-sample
+device side: `DeviceAugment` = the train-time transforms of `mae3d_transforms` (cast of the cached fp16 volume, three axis
+flips, intensity shift) as one HIP kernel."""
 from __future__ import annotations
 
 import torch
+
+
+class DeviceAugment:
+    """mae3d_transforms(mode='train') without the Gaussian smoothing (src/data/transforms.py:193-228) on a device batch:
+    CastToTyped(float32) -> RandFlipd(prob, axis 0/1/2) -> RandShiftIntensityd(offsets, prob).  Input: [B,C,S,S,S] fp16 (the
+    cache format, transforms.py:170-175), bf16 or fp32; output fp32.  Draws come from a torch generator on the host
+    (MONAI's numpy RandomState stream is not reproduced); `last_draw` exposes them for tests."""
+
+    def __init__(self, flip_prob: float = 0.1, shift_offsets: float = 0.1, shift_prob: float = 0.5, seed: int = 0):
+        self.flip_prob, self.shift_offsets, self.shift_prob = flip_prob, shift_offsets, shift_prob
+        self.gen = torch.Generator(device="cpu")
+        self.gen.manual_seed(seed)
+        self.last_draw = None
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        from . import _lib
+        lib = _lib.load()
+        if not x.is_cuda:
+            raise _lib.HctError("DeviceAugment runs on the GPU (libheadct_hip); no CPU fallback exists")
+        B, C, S = x.shape[0], x.shape[1], x.shape[2]
+        code = {torch.float16: _lib.HCT_F16, torch.bfloat16: _lib.HCT_BF16, torch.float32: _lib.HCT_F32}[x.dtype]
+        u = torch.rand(B, 5, generator=self.gen)
+        flip = ((u[:, 0] < self.flip_prob).to(torch.uint8) | ((u[:, 1] < self.flip_prob).to(torch.uint8) << 1)
+                | ((u[:, 2] < self.flip_prob).to(torch.uint8) << 2))
+        shift = torch.where(u[:, 3] < self.shift_prob, (u[:, 4] * 2 - 1) * self.shift_offsets, torch.zeros(B))
+        self.last_draw = (flip.clone(), shift.clone())
+        x = x.contiguous()
+        flip_d, shift_d = flip.to(x.device), shift.to(device=x.device, dtype=torch.float32)
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(lib.hct_augment_volume(x.data_ptr(), code, out.data_ptr(), B, C, S, flip_d.data_ptr(), shift_d.data_ptr(), st),
+                       "hct_augment_volume")
+        return out
 
 
 class SyntheticVolumes:

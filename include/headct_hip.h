@@ -28,6 +28,7 @@ extern "C" {
 
 #define HCT_F32 0
 #define HCT_BF16 1
+#define HCT_F16 2 /* IEEE half: input volumes of the persistent cache only (hct_augment_volume) */
 
 #define HCT_E_BADARG (-1)
 #define HCT_E_UNSUPPORTED (-2)
@@ -160,6 +161,15 @@ int hct_masked_mse(const void* pred, int pred_dtype, const float* x, const float
 /* reconstructed voxels: unpatchify (mae.py:172-192). pred rows [B, L(+1 if has_cls_row), pd] -> [B,C,S,S,S] fp32 */
 int hct_unpatchify(const void* pred, int pred_dtype, int has_cls_row, int B, int C, int S, int P, float* vol,
                    void* stream);
+
+/* Device side of the reference's per-sample MAE input transforms, mae3d_transforms(mode='train'), src/data/transforms.py:
+ * 193-228: CastToTyped(float32) of the cached volume (fp16 on disk, transforms.py:170-175) -> RandFlipd on spatial axes
+ * 0, 1, 2 -> RandShiftIntensityd.  The random draws stay on the host (one byte of flip flags and one offset per sample);
+ *   out[b, c, i, j, k] = (float)in[b, c, f0(i), f1(j), f2(k)] + shift[b],   f_a(t) = S-1-t if flip[b] bit a else t.
+ * in: [B, C, S, S, S] of in_dtype (HCT_F16 / HCT_BF16 / HCT_F32), out fp32 (may not alias in).  flip / shift may be NULL.
+ * RandGaussianSmoothd (transforms.py:230-238) is not part of this call. */
+int hct_augment_volume(const void* in, int in_dtype, float* out, int B, int C, int S, const unsigned char* flip,
+                       const float* shift, void* stream);
 
 /* Resume at another resolution: trilinear resize (align_corners = false) of the learnable position table
  * src [extra + g_src^3, D] -> dst [extra + g_dst^3, D], the `extra` leading (class) rows copied unchanged.

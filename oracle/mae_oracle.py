@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -201,6 +201,22 @@ def interpolate_pos_embed_3d(pos: torch.Tensor, new_grid: int, num_extra_tokens:
             for c_, (ic, wc) in enumerate(((i0t, w0), (i1t, w1))):
                 out += (wa[:, None, None, None] * wb[None, :, None, None] * wc[None, None, :, None]) * src[ia][:, ib][:, :, ic]
     return torch.cat([extra, out.reshape(1, new_grid ** 3, D)], dim=1)
+
+
+def augment_volume(x: torch.Tensor, flip: Optional[Sequence[int]] = None, shift: Optional[Sequence[float]] = None) -> torch.Tensor:
+    """Per-sample MAE input transforms with the random draws made explicit (src/data/transforms.py:193-228):
+    CastToTyped(float32) -> RandFlipd(spatial_axis=0), (1), (2) -> RandShiftIntensityd (img + offset, no clipping).
+    x: [B, C, S, S, S] of any float dtype (the persistent cache stores fp16, transforms.py:170-175);
+    flip[b]: bit a set = spatial axis a flipped; shift[b]: the drawn offset (0 when the transform did not fire)."""
+    out = x.to(torch.float32).clone()
+    for b in range(x.shape[0]):
+        f = int(flip[b]) if flip is not None else 0
+        dims = [1 + a for a in range(3) if f & (1 << a)]
+        v = out[b]
+        if dims:
+            v = torch.flip(v, dims)
+        out[b] = v + (np.float32(shift[b]) if shift is not None else np.float32(0))
+    return out
 
 
 def hash_uniform(n: int, seed: int) -> np.ndarray:

@@ -309,3 +309,32 @@ def test_pos_embed_interp3d_vs_oracle_and_reference_fixture(lib, cuda):
     torch.cuda.synchronize()
     want = O.interpolate_pos_embed_3d(t, 8, 1)
     assert torch.equal(dst[:, :1].cpu(), t[:, :1]) and float((dst.cpu() - want).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.bfloat16])
+def test_augment_volume_vs_oracle(lib, cuda, dtype):
+    """hct_augment_volume / DeviceAugment vs the oracle's restatement of the MAE input transforms (transforms.py:193-228).
+    The reference's transforms are MONAI's (absent): parity against MONAI itself is unpinned; flips and the shift are exact ops."""
+    from oracle import mae_oracle as O
+    from headct_foundation_amd.data import DeviceAugment
+    B, Cc, S = 9, 2, 16
+    x = _rand((B, Cc, S, S, S), cuda, torch.float32, 21).abs().to(dtype)
+    flips = torch.tensor([0, 1, 2, 3, 4, 5, 6, 7, 5], dtype=torch.uint8)
+    shifts = torch.tensor([0.0, 0.05, -0.1, 0.0, 0.0999, -0.03, 0.0, 0.07, 0.01])
+    out = torch.empty(B, Cc, S, S, S, device=cuda)
+    code = {torch.float16: _lib.HCT_F16, torch.bfloat16: _lib.HCT_BF16, torch.float32: _lib.HCT_F32}[dtype]
+    flips_d, shifts_d = flips.to(cuda), shifts.to(cuda)  # keep both alive: temporaries would share one allocator block
+    _lib.check(lib.hct_augment_volume(x.data_ptr(), code, out.data_ptr(), B, Cc, S, flips_d.data_ptr(), shifts_d.data_ptr(), _st()), "augment")
+    torch.cuda.synchronize()
+    want = O.augment_volume(x.cpu(), flips.tolist(), shifts.tolist())
+    assert torch.equal(out.cpu(), want)  # cast, index remap and one fp32 add: bit-exact
+    # NULL flags / offsets = plain cast
+    _lib.check(lib.hct_augment_volume(x.data_ptr(), code, out.data_ptr(), B, Cc, S, None, None, _st()), "augment")
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), x.cpu().float())
+    # host mirror: draws exposed, statistics of the draws as configured
+    aug = DeviceAugment(flip_prob=0.5, shift_offsets=0.1, shift_prob=0.5, seed=3)
+    y = aug(x)
+    f, sft = aug.last_draw
+    assert torch.equal(y.cpu(), O.augment_volume(x.cpu(), f.tolist(), sft.tolist()))
+    assert float(sft.abs().max()) <= 0.1
