@@ -592,7 +592,9 @@ int set_lds(F func, size_t bytes) {
 
 bool attention_mfma_supported(int N, int H, int dh) {
   (void)H;
-  return (dh == 48 || dh == 64) && bwd_lds(N) <= (size_t)kMaxLds;
+  // forward: K and V images; default backward: two phases of two images each (Q/dO, then K/V) -> N <= 608 tokens, which
+  // covers the ViT-L/128^3 decoder (513 tokens)
+  return (dh == 48 || dh == 64) && fwd_lds(N) <= (size_t)kMaxLds && bwd2_lds(N) <= (size_t)kMaxLds;
 }
 
 template <int DH, int NT>
@@ -627,7 +629,7 @@ int attention_fwd_mfma(const void* qkv, int B, int N, int H, int dh, void* o, fl
 int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const float* lse, int B, int N, int H, int dh,
                        void* dqkv, hipStream_t s) {
   const int Npad = npad_of(N);
-  if (!(g_attn_dbg & 4)) {
+  if (!(g_attn_dbg & 4) || bwd_lds(N) > (size_t)kMaxLds) {  // single-phase variant (testing hook) only where its 4 images fit
     const size_t l2 = bwd2_lds(N);
 #define HCT_BWD2(DH_, NW_)                                                                                           \
   do {                                                                                                               \

@@ -37,3 +37,8 @@ for dbg, nm in ((0, "two-phase 8 waves"), (8, "two-phase 4 waves"), (4, "single-
         (fu, ft), (bu, bt) = run(256, N, H, dh, 3)
         print(f"{tag} bwd [{nm}]: {bu:7.1f} us {bt:6.1f} TF")
 lib.hct_debug_force_simple_attention(10)
+
+# ViT-L/128^3 decoder (config #4): 513 tokens, 16 heads x 48 -- MFMA kernels vs the fp32-math fallback it used before
+for mode, nm in ((0, "mfma"), (1, "fp32-math kernels")):
+    (fu, ft), (bu, bt) = run(32, 513, 16, 48, mode, reps=3)
+    print(f"ViT-L decoder N=513 B=32 [{nm}] fwd {fu:8.1f} us {ft:6.1f} TF | bwd {bu:8.1f} us {bt:6.1f} TF")
