@@ -1428,7 +1428,10 @@ using namespace hct;
 extern "C" {
 
 void hct_set_cu_reserve(int n) { g_cu_reserve = n < 0 ? 0 : n; }
-void hct_debug_set_gemm_variant(int v) { g_nt_variant = v; }
+void hct_debug_set_gemm_variant(int v) {
+  if (v == -4 || v == -5) { g_w4_auto = v == -4; return; }  // -4 / -5: auto-dispatch of the 2-WG/CU variant on / off
+  g_nt_variant = v;
+}
 #ifdef HCT_STAMPS
 int hct_debug_set_stamp_buffer(void* p) {  // >= 64 * grid uint32 (diagnostic build only)
   return hct::check_hip(hipMemcpyToSymbol(HIP_SYMBOL(hct::g_stamp_ptr), &p, sizeof(p)), "stamp buffer");
