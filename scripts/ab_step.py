@@ -1,0 +1,52 @@
+"""Same-process A/B of the full training step (bench.py's workload) under a debug hook of the library.
+
+Between boxes the step time moves by +-0.5 ms, on one box by +-0.03 ms: small kernel changes are judged here, alternating
+blocks of steps with the hook off / on.   usage: python scripts/ab_step.py stagger0 | w4auto | <none>
+"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from headct_foundation_amd import MaskedAutoencoderViT, _lib
+from headct_foundation_amd.lr_sched import get_cosine_schedule_with_warmup
+from headct_foundation_amd.optim import HipAdamW, clip_gradients
+
+lib = _lib.load()
+HOOKS = {
+    "stagger0": (lambda: lib.hct_debug_set_gemm_stagger(0), lambda: lib.hct_debug_set_gemm_stagger(-1)),
+    "w4auto": (lambda: lib.hct_debug_set_gemm_variant(-4), lambda: lib.hct_debug_set_gemm_variant(-5)),
+    "none": (lambda: None, lambda: None),
+}
+name = sys.argv[1] if len(sys.argv) > 1 else "none"
+on, off = HOOKS[name]
+dev = torch.device("cuda", 0)
+torch.manual_seed(42)
+B = 256
+model = MaskedAutoencoderViT(**bench.VITB, compute_dtype="bf16").to(dev)
+opt = HipAdamW(model, lr=1.5e-4, weight_decay=5e-3, betas=(0.9, 0.95))
+sched = get_cosine_schedule_with_warmup(opt, 50, 1000, lr_end=1.5e-7)
+gen = torch.Generator(device=dev); gen.manual_seed(42)
+pool = [torch.rand(B, 1, 96, 96, 96, device=dev, generator=gen) for _ in range(2)]
+noises = [torch.rand(B, model.num_patches, device=dev, generator=gen) for _ in range(2)]
+
+
+def block(n):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(n):
+        opt.zero_grad()
+        loss, _, _ = model(pool[i % 2], noise=noises[i % 2])
+        loss.backward()
+        clip_gradients(model, 3.0)
+        opt.step(); sched.step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+block(5)
+res = {"off": [], "on": []}
+for rep in range(4):
+    off(); res["off"].append(block(10))
+    on(); res["on"].append(block(10))
+off()
+print(name, "off:", " ".join(f"{v:.3f}" for v in res["off"]), "| on:", " ".join(f"{v:.3f}" for v in res["on"]),
+      f"| mean off {sum(res['off'])/4:.3f} on {sum(res['on'])/4:.3f} ms/step")
