@@ -62,15 +62,15 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-def build_stamps_library(tag: str = "stamps", defines=("-DHCT_STAMPS",)) -> str:
+def build_stamps_library(tag: str = "stamps", defines=("-DHCT_STAMPS",), src: str = "gemm.hip") -> str:
     """Diagnostic variant for scripts/stamp_gemm.py: gemm.hip with -DHCT_STAMPS (in-kernel timestamps), rest unchanged."""
     build_library()
     hipcc = _hipcc()
-    op = os.path.join(OBJ, f"gemm_{tag}.o")
-    r = subprocess.run([hipcc] + FLAGS + list(defines) + ["-c", os.path.join(CSRC, "gemm.hip"), "-o", op], capture_output=True, text=True)
+    op = os.path.join(OBJ, f"{src[:-4]}_{tag}.o")
+    r = subprocess.run([hipcc] + FLAGS + list(defines) + ["-c", os.path.join(CSRC, src), "-o", op], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed (stamps):\n{r.stdout}\n{r.stderr}")
-    objs = [op if s == "gemm.hip" else os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [op if s == src else os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     out = os.path.join(HERE, f"libheadct_hip_{tag}.so")
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)
     if r.returncode != 0:
@@ -83,7 +83,13 @@ if __name__ == "__main__":
         print(build_stamps_library())
         sys.exit(0)
     if "--variant" in sys.argv:  # python -m headct_foundation_amd.build --variant TAG -DX=1 -DY=2   (diagnostic builds)
-        i = sys.argv.index("--variant")
-        print(build_stamps_library(sys.argv[i + 1], tuple(sys.argv[i + 2:])))
+        i = sys.argv.index("--variant")  # ... --variant TAG [--src attention_mfma.hip] -DX=1
+        rest = sys.argv[i + 2:]
+        src = "gemm.hip"
+        if "--src" in rest:
+            j = rest.index("--src")
+            src = rest[j + 1]
+            rest = rest[:j] + rest[j + 2:]
+        print(build_stamps_library(sys.argv[i + 1], tuple(rest), src))
         sys.exit(0)
     print(build_library(force="--force" in sys.argv, verbose=True))

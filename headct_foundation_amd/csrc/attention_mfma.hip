@@ -433,8 +433,11 @@ __device__ __forceinline__ bf16x8 gfrag(const bf16* __restrict__ base, int64_t r
 // the tile a wave owns comes from global memory (prefetched one tile ahead).  2 images + lse/delta = 58 KiB for 224
 // tokens, 4 waves per workgroup -> two (or three) workgroups per CU, so one workgroup's load phases (40 % of the old
 // single-phase kernel, which needed 112 KiB and ran alone on its CU) hide behind another's MFMA passes.
+#ifndef HCT_BWD2_WPE
+#define HCT_BWD2_WPE 4
+#endif
 template <int DH, int NW>
-__global__ void __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) attn_bwd2_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+__global__ void __launch_bounds__(NW * 64, (NW == 8 ? HCT_BWD2_WPE : 2)) attn_bwd2_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                                 const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                                 int N, int H, int Npad, bf16* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
