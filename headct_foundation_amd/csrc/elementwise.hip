@@ -109,9 +109,18 @@ __global__ void encoder_assemble_bwd_pos_kernel(const float* __restrict__ dh0, c
   const int l = blockIdx.x;
   for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) {
     f32x4 acc = {0, 0, 0, 0};
-    for (int b = 0; b < B; ++b) {
-      const int r = ids_restore[(size_t)b * L + l];
-      if (r < K) acc += Vec4<float>::load(dh0 + ((size_t)b * (K + 1) + 1 + r) * D + d);
+    // batches of 8 independent (index, row) loads; the additions keep the b order (bit-identical to the serial loop)
+    for (int b0 = 0; b0 < B; b0 += 8) {
+      int r[8];
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = b0 + u < B ? ids_restore[(size_t)(b0 + u) * L + l] : K;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = r[u] < K ? Vec4<float>::load(dh0 + ((size_t)(b0 + u) * (K + 1) + 1 + r[u]) * D + d) : f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r[u] < K) acc += v[u];
     }
     Vec4<float>::store(dpos + (size_t)l * D + d, acc);
   }
@@ -122,7 +131,14 @@ __global__ void strided_rowsum_kernel(const float* __restrict__ src, int B, size
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= D) return;
   float acc = 0.f;
-  for (int b = 0; b < B; ++b) acc += src[(size_t)b * stride + d];
+  for (int b0 = 0; b0 < B; b0 += 16) {  // 16 loads in flight, additions in b order
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = b0 + u < B ? src[(size_t)(b0 + u) * stride + d] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (b0 + u < B) acc += v[u];
+  }
   out[d] = acc;
 }
 
@@ -311,9 +327,16 @@ __global__ void decoder_assemble_bwd_reduce_kernel(const float* __restrict__ dy,
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
       const float* base = dy + (size_t)b * (L + 1) * D;
       ac += Vec4<float>::load(base + d);
-      for (int j = K; j < L; ++j) {
-        const int l = ids_shuffle[(size_t)b * L + j];
-        am += Vec4<float>::load(base + (size_t)(1 + l) * D + d);
+      for (int j0 = K; j0 < L; j0 += 8) {  // 8 independent (index, row) loads; additions in j order
+        int l[8];
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) l[u] = j0 + u < L ? ids_shuffle[(size_t)b * L + j0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = Vec4<float>::load(base + (size_t)(1 + l[u]) * D + d);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (j0 + u < L) am += v[u];
       }
     }
     Vec4<float>::store(partial + ((size_t)blockIdx.x * 2 + 0) * D + d, am);
@@ -410,7 +433,14 @@ __global__ void __launch_bounds__(256) loss_fold_kernel(const float* __restrict_
                                                         float* __restrict__ loss) {
   __shared__ float s_tmp[4];
   float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) s += row_loss[i];
+  for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 8) {  // 8 loads in flight per thread, additions in index order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = i0 + u * 256 < n ? row_loss[i0 + u * 256] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * 256 < n) s += v[u];
+  }
   s = block_sum_256(s, s_tmp);
   if (threadIdx.x == 0) *loss = s * inv_masksum;
 }
