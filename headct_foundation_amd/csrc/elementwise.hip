@@ -270,7 +270,14 @@ __global__ void __launch_bounds__(512) fold_partials_kernel(const float* __restr
   if (out == nullptr) return;
   float acc = 0.f;
   if (d < D)
-    for (int b = rg; b < nblk; b += 16) acc += partial[((size_t)b * nq_stride + q) * D + d];
+    for (int b0 = rg; b0 < nblk; b0 += 16 * 8) {  // 8 loads in flight per thread, additions in block order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = b0 + 16 * u < nblk ? partial[((size_t)(b0 + 16 * u) * nq_stride + q) * D + d] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (b0 + 16 * u < nblk) acc += v[u];
+    }
   s_red[rg][c] = acc;
   __syncthreads();
   if (rg == 0 && d < D) {
