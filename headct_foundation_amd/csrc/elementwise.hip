@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restr
 // registers (NV compile-time) and are reduced over the block's 4 waves through LDS, then written to
 // partial[block][3][D]; a second kernel folds the partials in fixed order (deterministic).
 // =============================================================================================
-constexpr int kLnBwdBlocks = 512;
+constexpr int kLnBwdBlocks = 1024;  // 4 workgroups = 16 waves per CU (36 KB of LDS each): the row loop is a load -> reduce -> store chain per wave
 
 template <typename T, typename TS, int NV>
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
