@@ -178,6 +178,62 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restr
   }
 }
 
+// Register-resident variant (D <= 256 * NV): the row is loaded once (the kernel above reads it three times, one memory round
+// trip per pass), each wave walks rows w, w+W, ... with gamma / beta held in registers.  Same arithmetic in the same order.
+template <typename T, int NV>
+__global__ void __launch_bounds__(256) layernorm_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int rows, int D, float eps,
+                                                                T* __restrict__ y, float* __restrict__ mean,
+                                                                float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  f32x4 g[NV], bt[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int d = lane * 4 + 256 * i;
+    g[i] = d < D ? Vec4<float>::load(gamma + d) : f32x4{0, 0, 0, 0};
+    bt[i] = d < D ? Vec4<float>::load(beta + d) : f32x4{0, 0, 0, 0};
+  }
+  for (int row = wid; row < rows; row += nw) {
+    const float* xr = x + (size_t)row * D;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int d = lane * 4 + 256 * i;
+      if (d < D) {
+        v[i] = Vec4<float>::load(xr + d);
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int d = lane * 4 + 256 * i;
+      if (d < D) {
+        const f32x4 c = v[i] - mu;
+        q += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+    T* yr = y + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int d = lane * 4 + 256 * i;
+      if (d < D) {
+        f32x4 o = (v[i] - mu) * rs;
+        o = o * g[i] + bt[i];
+        Vec4<T>::store(yr + d, o);
+      }
+    }
+  }
+}
+
 // =============================================================================================
 // LayerNorm backward + residual-gradient add + column partials (dgamma, dbeta, colsum(dx_total)).
 //   dx = rstd * (dy*g - mean_d(dy*g) - xhat * mean_d(dy*g*xhat));   dx_total = dres + dx
@@ -690,9 +746,20 @@ int hct_layernorm_fwd(const float* x, const float* gamma, const float* beta, int
                       int y_dtype, float* mean, float* rstd, void* stream) {
   HCT_REQUIRE(D % 4 == 0 && rows >= 0, "hct_layernorm_fwd: bad shape rows=%d D=%d", rows, D);
   if (rows == 0) return 0;
-  HCT_DISPATCH_DTYPE(y_dtype, T,
-                     hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                                        x, gamma, beta, rows, D, eps, (T*)y, mean, rstd));
+  const int nblk = min((rows + 3) / 4, 2048);  // 8 workgroups (32 waves) per CU, each wave strides over rows
+#define HCT_LN_FWD(NV_)                                                                                                 \
+  HCT_DISPATCH_DTYPE(y_dtype, T,                                                                                       \
+                     hipLaunchKernelGGL((layernorm_fwd_reg_kernel<T, NV_>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, \
+                                        gamma, beta, rows, D, eps, (T*)y, mean, rstd))
+  if (D <= 256) HCT_LN_FWD(1);
+  else if (D <= 512) HCT_LN_FWD(2);
+  else if (D <= 768) HCT_LN_FWD(3);
+  else if (D <= 1024) HCT_LN_FWD(4);
+  else
+    HCT_DISPATCH_DTYPE(y_dtype, T,
+                       hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                                          x, gamma, beta, rows, D, eps, (T*)y, mean, rstd));
+#undef HCT_LN_FWD
   HCT_CHECK_LAUNCH("hct_layernorm_fwd");
   return 0;
 }
