@@ -11,6 +11,8 @@ from headct_foundation_amd import MaskedAutoencoderViT, _lib
 from headct_foundation_amd.lr_sched import get_cosine_schedule_with_warmup
 from headct_foundation_amd.optim import HipAdamW, clip_gradients
 
+if os.environ.get('HCT_LIB_TAG'):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"libheadct_hip_{os.environ['HCT_LIB_TAG']}.so")
 lib = _lib.load()
 HOOKS = {
     "stagger0": (lambda: lib.hct_debug_set_gemm_stagger(0), lambda: lib.hct_debug_set_gemm_stagger(-1)),
