@@ -40,12 +40,18 @@ class DistributedDataParallel(nn.Module):
             dist.broadcast(module._flat, src=0, group=process_group)  # DDP ctor: rank 0's parameters win
             if hasattr(module, "mark_weights_updated"):
                 module.mark_weights_updated()
+        # Persistent GEMM workgroups fill every CU's register file and LDS: while a gradient all-reduce is in flight a few
+        # CUs are left free for the RCCL kernels, otherwise the GEMM workgroups that find no CU start only when the others
+        # have finished (HCT_CU_RESERVE overrides the count; 0 disables).  The reserve is switched on with the first bucket
+        # of a backward and off again when the collectives have been waited for, so the forward pass and the part of
+        # the backward before the first bucket keep all CUs.
+        self._reserve = 0
+        self._set_reserve = None
         if self.world_size > 1 and getattr(module, "_flat", None) is not None and module._flat.is_cuda:
-            # persistent GEMM workgroups fill every CU's register file: keep a few CUs free for the RCCL kernels that
-            # run concurrently with the backward (HCT_CU_RESERVE overrides; 0 disables)
             import os
             from . import _lib
-            _lib.load().hct_set_cu_reserve(int(os.environ.get("HCT_CU_RESERVE", "16")))
+            self._reserve = int(os.environ.get("HCT_CU_RESERVE", "16"))
+            self._set_reserve = _lib.load().hct_set_cu_reserve
         module._grad_prescale = 1.0 / self.world_size
         module._bucket_hook = self._on_stage
         module._post_backward_hook = self._finish
@@ -71,6 +77,8 @@ class DistributedDataParallel(nn.Module):
             self._open = None
 
     def _launch(self, begin: int, end: int) -> None:
+        if self._set_reserve is not None and not self._works and self._reserve > 0:
+            self._set_reserve(self._reserve)  # GEMMs enqueued from here on run beside the collective
         view = self.module._flat_grad[begin:end]
         self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
         self.launched.append((begin, end))
@@ -84,6 +92,8 @@ class DistributedDataParallel(nn.Module):
         for w in self._works:
             w.wait()  # compute stream waits for the collective (no host block on NCCL/RCCL)
         self._works = []
+        if self._set_reserve is not None and self._reserve > 0:
+            self._set_reserve(0)
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
