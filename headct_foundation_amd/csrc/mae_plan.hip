@@ -134,6 +134,30 @@ __global__ void __launch_bounds__(256) transpose_cast_batched_kernel(const float
   const int r0 = (local / tcols) * 64, c0 = (local % tcols) * 64;
   const float* s = src + t.src[lo];
   bf16* d = dst + t.dst[lo];
+  // reads: 16 lanes x 16 B per source row (4 rows per wave-instruction); writes: 16 lanes x 8 B per destination row.  All
+  // weight matrices of the path have rows and cols that are multiples of 4 (plan creation checks the dims).
+  const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;  // 16 quads x 16 row slots
+  const bool vec = (cols & 3) == 0 && (rows & 3) == 0;
+  if (vec) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + rr + 16 * i, c = c0 + q * 4;
+      f32x4 v = {0, 0, 0, 0};
+      if (r < rows && c < cols) v = Vec4<float>::load(s + (size_t)r * cols + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[rr + 16 * i][q * 4 + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + rr + 16 * i, r = r0 + q * 4;
+      if (c < cols && r < rows) {
+        const f32x4 v = {tile[q * 4 + 0][rr + 16 * i], tile[q * 4 + 1][rr + 16 * i], tile[q * 4 + 2][rr + 16 * i], tile[q * 4 + 3][rr + 16 * i]};
+        Vec4<bf16>::store(d + (size_t)c * rows + r, v);
+      }
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
     const int r = r0 + i, c = c0 + tx;
