@@ -2,3 +2,4 @@
 from .mae import MaskedAutoencoderViT, build_sincos_position_embedding  # noqa: F401
 from ._lib import HctError  # noqa: F401
 from .pos_embed import interpolate_pos_embed  # noqa: F401
+from .vit import ViT  # noqa: F401

@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libheadct_hip.so")
 
 HCT_F32, HCT_BF16, HCT_F16 = 0, 1, 2
+HCT_ACT_NONE, HCT_ACT_GELU, HCT_ACT_DGELU = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
 
 c_void_p, c_int, c_float, c_size_t, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
@@ -73,6 +74,7 @@ _PROTOS = {
                                          c_void_p, c_size_t, c_void_p]),
     "hct_masked_mse": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hct_unpatchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "hct_vit_assemble_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "hct_augment_volume": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "hct_pos_embed_interp3d": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "hct_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -614,6 +614,30 @@ static int launch_ln_bwd(const void* dy, const float* x, const float* mean, cons
   return 0;
 }
 
+// ViT encoder input (vit.py:144-162): class token, register tokens, position-embedded patch tokens
+namespace hct {
+template <typename T>
+__global__ void vit_assemble_fwd_kernel(const T* __restrict__ tok, const float* __restrict__ cls, const float* __restrict__ reg,
+                                        const float* __restrict__ pos, int L, int R, int D, float* __restrict__ h, int64_t total4) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total4) return;
+  const int d4 = D >> 2, T1 = 1 + R + L;
+  const int c = (int)(gid % d4) * 4;
+  const int64_t row = gid / d4;
+  const int t = (int)(row % T1);
+  const int64_t b = row / T1;
+  f32x4 v;
+  if (t == 0) v = Vec4<float>::load(cls + c);
+  else if (t <= R) v = Vec4<float>::load(reg + (int64_t)(t - 1) * D + c);
+  else {
+    const int l = t - 1 - R;
+    v = Vec4<T>::load(tok + (b * L + l) * D + c);
+    if (pos) v += Vec4<float>::load(pos + (int64_t)l * D + c);
+  }
+  Vec4<float>::store(h + row * D + c, v);
+}
+}  // namespace hct
+
 // input transforms (transforms.py:193-228): cast + per-sample axis flips + intensity shift; one thread per 4 voxels of the
 // innermost axis (a flipped innermost axis is read as a reversed group of 4)
 namespace hct {
@@ -941,6 +965,17 @@ int hct_augment_volume(const void* in, int in_dtype, float* out, int B, int C, i
   else if (in_dtype == HCT_BF16) hipLaunchKernelGGL(hct::augment_volume_kernel<hct::bf16>, grid, block, 0, s, (const hct::bf16*)in, out, C, S, flip, shift, n4);
   else hipLaunchKernelGGL(hct::augment_volume_kernel<_Float16>, grid, block, 0, s, (const _Float16*)in, out, C, S, flip, shift, n4);
   HCT_CHECK_LAUNCH("hct_augment_volume");
+  return 0;
+}
+
+int hct_vit_assemble_fwd(const void* tok, int tok_dtype, const float* cls, const float* reg, const float* pos, int B,
+                         int L, int R, int D, float* h, void* stream) {
+  HCT_REQUIRE(tok && cls && h && B > 0 && L > 0 && R >= 0 && D > 0 && D % 4 == 0 && (R == 0 || reg), "hct_vit_assemble_fwd: bad arguments");
+  const int64_t n4 = (int64_t)B * (1 + R + L) * (D / 4);
+  HCT_DISPATCH_DTYPE(tok_dtype, T,
+                     hipLaunchKernelGGL(hct::vit_assemble_fwd_kernel<T>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
+                                        (hipStream_t)stream, (const T*)tok, cls, reg, pos, L, R, D, h, n4));
+  HCT_CHECK_LAUNCH("hct_vit_assemble_fwd");
   return 0;
 }
 }  // extern "C"

@@ -162,6 +162,12 @@ int hct_masked_mse(const void* pred, int pred_dtype, const float* x, const float
 int hct_unpatchify(const void* pred, int pred_dtype, int has_cls_row, int B, int C, int S, int P, float* vol,
                    void* stream);
 
+/* Feature-extraction input of the plain ViT encoder (src/models/vit.py:144-162): every patch is embedded, the class token
+ * is prepended and the optional register tokens are inserted behind it:
+ *   h[b,0,:] = cls;  h[b,1+r,:] = reg[r,:] (r < R);  h[b,1+R+l,:] = tok[b*L+l,:] + pos[l,:]        (pos / reg may be NULL) */
+int hct_vit_assemble_fwd(const void* tok, int tok_dtype, const float* cls, const float* reg, const float* pos, int B,
+                         int L, int R, int D, float* h, void* stream);
+
 /* Device side of the reference's per-sample MAE input transforms, mae3d_transforms(mode='train'), src/data/transforms.py:
  * 193-228: CastToTyped(float32) of the cached volume (fp16 on disk, transforms.py:170-175) -> RandFlipd on spatial axes
  * 0, 1, 2 -> RandShiftIntensityd.  The random draws stay on the host (one byte of flip flags and one offset per sample);

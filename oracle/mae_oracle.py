@@ -389,6 +389,41 @@ def forward(cfg: MAEConfig, p: Dict[str, torch.Tensor], x: torch.Tensor, noise: 
     return loss, pred, mask, inter
 
 
+def make_vit_params(shapes: Dict[str, Sequence[int]], seed0: int = 100) -> Dict[str, torch.Tensor]:
+    """Deterministic non-trivial values for a ViT state dict (fixtures): hash stream i per tensor in sorted key order,
+    x0.02 for matrices, x0.1 for vectors, +1 on LayerNorm weights."""
+    out = {}
+    for i, n in enumerate(sorted(shapes)):
+        shp = tuple(int(v) for v in shapes[n])
+        numel = int(np.prod(shp))
+        scale = 0.02 if len(shp) > 1 else 0.1
+        t = torch.from_numpy(hash_uniform(numel, seed0 + i).reshape(shp).astype(np.float32)) * scale
+        if n.endswith("norm.weight"):
+            t = t + 1.0
+        out[n] = t
+    return out
+
+
+def vit_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, patch_size: int, num_heads: int, num_layers: int):
+    """ViT.forward without a classification head, src/models/vit.py:144-173: embed EVERY patch (+ position table), prepend
+    the class token, insert the register tokens behind it (:150-160), run the blocks collecting each output, final
+    LayerNorm with eps 1e-6 (:124).  Returns (x, hidden_states_out)."""
+    B = x.shape[0]
+    tok = F.conv3d(x, p["patch_embedding.patch_embeddings.weight"], p["patch_embedding.patch_embeddings.bias"], stride=patch_size)
+    tok = tok.flatten(2).transpose(-1, -2)
+    if "patch_embedding.position_embeddings" in p:
+        tok = tok + p["patch_embedding.position_embeddings"]
+    h = torch.cat((p["cls_token"].expand(B, -1, -1), tok), dim=1)
+    if "register_tokens" in p:
+        h = torch.cat((h[:, :1], p["register_tokens"].expand(B, -1, -1), h[:, 1:]), dim=1)
+    hidden = []
+    for i in range(num_layers):
+        h = _block(p, f"blocks.{i}", h, num_heads, None, "")
+        hidden.append(h)
+    out = F.layer_norm(h, (h.shape[-1],), p["norm.weight"], p["norm.bias"], 1e-6)
+    return out, hidden
+
+
 def forward_backward(cfg: MAEConfig, params: Dict[str, torch.Tensor], x: torch.Tensor, noise: torch.Tensor,
                      want_inter: bool = False):
     """loss + autograd gradients of every trainable parameter (engine_pretrain_mae.py:58-62, AMP off)."""

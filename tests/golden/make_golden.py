@@ -282,6 +282,28 @@ def sincos_fixture():
         json.dump(out, f)
 
 
+def vit_fixture():
+    """ViT.forward (feature extraction, src/models/vit.py:144-173) with register tokens and a learnable position table."""
+    from src.models.vit import ViT
+    torch.manual_seed(11)
+    kw = dict(in_chans=1, img_size=(32, 32, 32), patch_size=(16, 16, 16), hidden_size=192, mlp_dim=384, num_layers=2, num_heads=3,
+              patch_embed="conv", pos_embed="learnable", classification=False, num_register_tokens=2, qkv_bias=False)
+    ref = ViT(**kw).eval()
+    params = O.make_vit_params({k: list(v.shape) for k, v in ref.state_dict().items()})  # cls / register tokens start as zeros
+    ref.load_state_dict(params, strict=True)
+    x = torch.from_numpy(O.hash_uniform(2 * 32 ** 3, 7).reshape(2, 1, 32, 32, 32).astype(np.float32)) * 0.5 + 0.5
+    with torch.no_grad():
+        out, hidden = ref(x)
+    o_out, o_hidden = O.vit_forward(params, x, 16, 3, 2)
+    err = max(float((out - o_out).abs().max()), *(float((a - b).abs().max()) for a, b in zip(hidden, o_hidden)))
+    assert out.shape == (2, 1 + 2 + 8, 192) and err < 5e-6, err
+    fx = dict(ctor=dict(kw, img_size=32, patch_size=16), max_abs_dev_oracle=err,
+              state_dict={k: dict(shape=list(v.shape)) for k, v in ref.state_dict().items()},  # the reference's key order
+              out=sample(out, 512), hidden=[sample(h, 256) for h in hidden])
+    with open(os.path.join(HERE, "vit_features.json"), "w") as f:
+        json.dump(fx, f)
+
+
 def pos_interp_fixture():
     """interpolate_pos_embed (pos_embed.py:102-153) on a learnable table, up- and down-sampling; full outputs (small)."""
     from src.utils.pos_embed import interpolate_pos_embed
@@ -311,6 +333,7 @@ if __name__ == "__main__":
     sincos_fixture()
     lr_schedule_fixture()
     pos_interp_fixture()
+    vit_fixture()
     run_case("micro", 2, 0, full=True)
     run_case("yaml_cut", 2, 1, full=False)
     run_case("tiny", 2, 0, full=False)

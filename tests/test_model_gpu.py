@@ -20,7 +20,7 @@ def _run_hip(cfg, params, x, noise, device, dtype):
     assert a is None and b is None
     loss.backward()
     torch.cuda.synchronize()
-    return model, float(loss)
+    return model, float(loss.detach())
 
 
 @pytest.mark.parametrize("name,batch,seed", CASES)
@@ -123,3 +123,27 @@ def test_train_curve_fp32_vs_golden(lib, cuda):
             got, want, l2, l2w = sample_of(named[k], entry)
             atol = 4 * hp["base_lr"] if k.endswith("qkv.bias") else 1e-5
             assert torch.allclose(got, want, rtol=1e-4, atol=atol), k
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
+def test_vit_feature_extraction_vs_oracle_and_reference_fixture(lib, cuda, dtype, tol):
+    """HIP ViT (forward only, register tokens, final LN eps 1e-6) vs the oracle and the reference-generated fixture."""
+    import json, os
+    from headct_foundation_amd import ViT
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vit_features.json")))
+    ctor = dict(fx["ctor"])
+    params = O.make_vit_params({k: v["shape"] for k, v in fx["state_dict"].items()})
+    x = torch.from_numpy(O.hash_uniform(2 * 32 ** 3, 7).reshape(2, 1, 32, 32, 32).astype(np.float32)) * 0.5 + 0.5
+    model = ViT(**ctor, compute_dtype=dtype)
+    assert list(model.state_dict().keys()) == list(fx["state_dict"].keys())  # names and registration order of vit.py:100-130
+    model.load_state_dict(params, strict=True)
+    model = model.to(cuda)
+    out, hidden = model(x.to(cuda))
+    o_out, o_hidden = O.vit_forward(params, x, 16, 3, 2)
+    assert rel_err(out, o_out) < tol
+    for a, b in zip(hidden, o_hidden):
+        assert rel_err(a, b) < tol
+    if dtype == "fp32":
+        for t, entry in [(out, fx["out"])] + list(zip(hidden, fx["hidden"])):
+            got, want, l2, l2w = sample_of(t, entry)
+            assert torch.allclose(got, want, rtol=1e-3, atol=1e-4)

@@ -111,3 +111,20 @@ def test_pos_embed_interpolation_against_reference_fixture():
     o = O.interpolate_pos_embed_3d(t, 3, 1)
     assert o.shape == (1, 28, 4) and torch.equal(o[:, :1], t[:, :1])
     assert torch.equal(O.interpolate_pos_embed_3d(t, 2, 1), t)
+
+
+def test_vit_feature_extraction_against_reference_fixture():
+    """oracle.vit_forward vs the reference's ViT.forward (src/models/vit.py:144-173): register tokens, final LN eps 1e-6."""
+    import json, os
+    import numpy as np
+    import torch
+    from oracle import mae_oracle as O
+    from tests.util import sample_of
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vit_features.json")))
+    params = O.make_vit_params({k: v["shape"] for k, v in fx["state_dict"].items()})
+    x = torch.from_numpy(O.hash_uniform(2 * 32 ** 3, 7).reshape(2, 1, 32, 32, 32).astype(np.float32)) * 0.5 + 0.5
+    out, hidden = O.vit_forward(params, x, 16, 3, 2)
+    assert list(out.shape) == fx["out"]["shape"] == [2, 11, 192] and len(hidden) == 2
+    for t, entry in [(out, fx["out"])] + list(zip(hidden, fx["hidden"])):
+        got, want, l2, l2w = sample_of(t, entry)
+        assert torch.allclose(got, want, rtol=0, atol=5e-6) and abs(l2 - l2w) < 1e-4 * l2w
