@@ -17,6 +17,7 @@ lib = _lib.load()
 HOOKS = {
     "stagger0": (lambda: lib.hct_debug_set_gemm_stagger(0), lambda: lib.hct_debug_set_gemm_stagger(-1)),
     "w4auto": (lambda: lib.hct_debug_set_gemm_variant(-4), lambda: lib.hct_debug_set_gemm_variant(-5)),
+    "tile256": (lambda: lib.hct_debug_set_gemm_variant(256), lambda: lib.hct_debug_set_gemm_variant(0)),  # on = 256-row tiles only
     "none": (lambda: None, lambda: None),
 }
 name = sys.argv[1] if len(sys.argv) > 1 else "none"

@@ -39,9 +39,9 @@ def call(name, M, N, K, out_f32=False, bias=False, residual=False, act=0, tn=Fal
     print(f"  {name:34s} M={M:6d} N={N:5d} K={K:6d}  {2.0*M*N*K/us/1e6:7.1f} TF  {us:7.1f} us")
     return us
 
-for tag, M, var in (("decoder", 256 * 217, 256), ("decoder", 256 * 217, 4), ("encoder", 256 * 55, 256), ("encoder", 256 * 55, 4)):
+for tag, M, var in (("decoder", 256 * 217, 256), ("decoder", 256 * 217, 0), ("decoder", 256 * 217, 4), ("encoder", 256 * 55, 256), ("encoder", 256 * 55, 0), ("encoder", 256 * 55, 4)):
     lib.hct_debug_set_gemm_variant(var)
-    print(tag, "block, forward + backward GEMMs, NT variant", var)
+    print(tag, "block, forward + backward GEMMs, NT variant", var, "(0 = auto: 192- or 256-row tiles)" if var == 0 else "")
     t = 0
     t += call("qkv fwd (plain bf16)", M, 2304, 768)
     t += call("proj fwd (+bias +residual, f32)", M, 768, 768, out_f32=True, bias=True, residual=True)
