@@ -437,7 +437,10 @@ __device__ __forceinline__ f32x4 bload_bf16x4(__amdgpu_buffer_rsrc_t r, uint32_t
 // vmcnt(0) serialised the whole store stream: ~20 us per 256x256 tile).
 // Epilogue traffic is streamed once: non-temporal policy (aux = 2) keeps it from displacing the A/B panels that the
 // LDS-DMA stream re-reads through L2 (measured +9..16 % on the N >= 2304, K = 768 GEMMs).
-constexpr int kNT = 2;
+#ifndef HCT_EPI_CACHE_POLICY
+#define HCT_EPI_CACHE_POLICY 2  /* nt */
+#endif
+constexpr int kNT = HCT_EPI_CACHE_POLICY;
 
 // Lane -> output mapping of the specialised epilogue:
 //   bf16 outputs ("wide" modes): lane = 4 rows x 16 lanes, 8 consecutive columns (16 B) per lane -> dwordx4 stores / loads.
