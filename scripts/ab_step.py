@@ -18,6 +18,9 @@ HOOKS = {
     "stagger0": (lambda: lib.hct_debug_set_gemm_stagger(0), lambda: lib.hct_debug_set_gemm_stagger(-1)),
     "w4auto": (lambda: lib.hct_debug_set_gemm_variant(-4), lambda: lib.hct_debug_set_gemm_variant(-5)),
     "tile256": (lambda: lib.hct_debug_set_gemm_variant(256), lambda: lib.hct_debug_set_gemm_variant(0)),  # on = 256-row tiles only
+    "attn_online": (lambda: lib.hct_debug_force_simple_attention(2), lambda: lib.hct_debug_force_simple_attention(3)),  # on = online-softmax forward
+    "attn_bwd1": (lambda: lib.hct_debug_force_simple_attention(14), lambda: lib.hct_debug_force_simple_attention(10)),  # on = single-phase backward
+    "attn_bwd4w": (lambda: lib.hct_debug_force_simple_attention(18), lambda: lib.hct_debug_force_simple_attention(10)),  # on = 4-wave two-phase backward
     "none": (lambda: None, lambda: None),
 }
 name = sys.argv[1] if len(sys.argv) > 1 else "none"
