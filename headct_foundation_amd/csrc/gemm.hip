@@ -699,14 +699,14 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
 #pragma unroll
     for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const bf16x8*>(sb + j * 1024);
   };
+  // (no s_setprio around the MFMA groups: raising the priority of the issuing wave starves its SIMD partner's LDS reads
+  //  and DMA issue -- 0.55 ms of the 43.8 ms step, scripts/ab_step.py)
   auto mma = [&](int half, const bf16x8* af, const bf16x8* bq) {
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][half * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[i][half * 4 + j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
   };
   // stage landed: own DMA retired (leaving `later` younger stages in flight) + barrier
   auto land = [&](int later) {
@@ -916,13 +916,11 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_nt_w4_kernel(int M, int N, i
     for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const bf16x8*>(sb + j * 1024);
   };
   auto mma = [&](int half, const bf16x8* af, const bf16x8* bq) {
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][half * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[i][half * 4 + j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
   };
   // own DMA retired (leaving `later` younger stages = 6 loads each in flight), every fragment read issued so far has
   // returned (so the buffer of the current stage may be refilled right after), then barrier
@@ -1105,24 +1103,20 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
     for (int j = 0; j < 4; ++j) bq[j] = frag(sb, wn * 8 + half * 4 + j);
   };
   auto mma = [&](int half, const bf16x8* af, const bf16x8* bq) {
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][half * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[i][half * 4 + j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
   };
   // half of a half-stage (rows 32*part .. 32*part+31 of the wave tile): lets the 16 transposed reads of the next stage be
   // issued as 8 + 8 around it, so no wait ever needs more than the 15 outstanding LDS ops lgkmcnt can express
   auto mma_part = [&](int half, int part, const bf16x8* af, const bf16x8* bq) {
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 2 * part; i < 2 * part + 2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][half * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[i][half * 4 + j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
   };
   auto land = [&](int later) {
     if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
