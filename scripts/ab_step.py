@@ -21,6 +21,8 @@ HOOKS = {
     "attn_online": (lambda: lib.hct_debug_force_simple_attention(2), lambda: lib.hct_debug_force_simple_attention(3)),  # on = online-softmax forward
     "attn_bwd1": (lambda: lib.hct_debug_force_simple_attention(14), lambda: lib.hct_debug_force_simple_attention(10)),  # on = single-phase backward
     "attn_bwd4w": (lambda: lib.hct_debug_force_simple_attention(18), lambda: lib.hct_debug_force_simple_attention(10)),  # on = 4-wave two-phase backward
+    "stagger2": (lambda: lib.hct_debug_set_gemm_stagger(2), lambda: lib.hct_debug_set_gemm_stagger(-1)),
+    "stagger4": (lambda: lib.hct_debug_set_gemm_stagger(4), lambda: lib.hct_debug_set_gemm_stagger(-1)),
     "none": (lambda: None, lambda: None),
 }
 name = sys.argv[1] if len(sys.argv) > 1 else "none"
