@@ -89,14 +89,14 @@ __device__ __forceinline__ float dgelu_erf(float x) {
 // relative rounding): one v_rcp + one v_exp + 6 FMAs instead of erff's ~30-instruction polynomial branches.  gelu and
 // gelu' share the exponential (exp(-x^2/2) is both erf's tail factor and the Gaussian pdf).
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  const float E = __expf(-z * z);
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float half_tail = 0.5f * p * t * E;            // 0.5 * (1 - erf(z))
+  // constants folded: |x|/sqrt2 into the rcp argument, log2(e) into the exponent, the 0.5 into the polynomial
+  const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752440f, 1.0f));
+  const float E = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));
+  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = fmaf(p, t, 0.5f * 1.421413741f);
+  p = fmaf(p, t, 0.5f * -0.284496736f);
+  p = fmaf(p, t, 0.5f * 0.254829592f);
+  const float half_tail = p * t * E;  // 0.5 * (1 - erf(|x| / sqrt 2)), |abs err| <= 3e-7
   cdf = x >= 0.f ? 1.0f - half_tail : half_tail;
   pdf = 0.39894228040143267794f * E;
 }
