@@ -82,7 +82,7 @@ __device__ __forceinline__ void compute_delta(const bf16* __restrict__ ob, const
       if (idx < total && (idx & 7) == 0) {
         const int r = idx >> 3;
         sDel[r] = r < N ? part : 0.f;
-        sLse[r] = r < N ? lse_row[r] : INFINITY;  // padded query rows: p = exp(s - inf) = 0
+        sLse[r] = r < N ? lse_row[r] * 1.44269504088896340736f : INFINITY;  // base-2 (see exp2 below); padded rows: p = 0
       }
     }
   }
@@ -139,6 +139,7 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma_kernel(const bf16* __restri
   load_image<DH>(Vimg, qb + 2 * H * DH, rs, N, Npad, 256);
   __syncthreads();
   const float scale = rsqrtf((float)DH);
+  const float scale2 = scale * 1.44269504088896340736f;  // softmax probabilities are rebuilt in base 2 (lse is stored * log2 e)
   const int g = lane >> 4;
   constexpr int ND = DH / 16;
   const int nqt = (N + 15) >> 4;
@@ -318,6 +319,7 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
   compute_delta<DH>(ob, dob, os, lse + (int64_t)bh * N, N, Npad, sLse, sDel, 512);
   __syncthreads();
   const float scale = rsqrtf((float)DH);
+  const float scale2 = scale * 1.44269504088896340736f;  // softmax probabilities are rebuilt in base 2 (lse is stored * log2 e)
   const int g = lane >> 4;
   constexpr int ND = DH / 16;
   const int ntile = Npad >> 4, npair = Npad >> 5;
@@ -350,7 +352,7 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
         const f32x4 D4 = *reinterpret_cast<const f32x4*>(sDel + q0 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = key_ok ? __expf(s[r] * scale - L4[r]) : 0.f;
+          const float p = key_ok ? __builtin_amdgcn_exp2f(s[r] * scale2 - L4[r]) : 0.f;
           P[hh][r] = p;
           dS[hh][r] = p * (dp[r] - D4[r]) * scale;
         }
@@ -400,7 +402,7 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = (k0 + 4 * g + r < N) ? __expf(s[r] * scale - Lq) : 0.f;
+          const float p = (k0 + 4 * g + r < N) ? __builtin_amdgcn_exp2f(s[r] * scale2 - Lq) : 0.f;
           dS[hh][r] = p * (dp[r] - Dq) * scale;
         }
       }
@@ -455,6 +457,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? HCT_BWD2_WPE : 2)) attn_bw
   const bf16* ob = o + (int64_t)b * N * os + h * DH;
   const bf16* dob = d_o + (int64_t)b * N * os + h * DH;
   const float scale = rsqrtf((float)DH);
+  const float scale2 = scale * 1.44269504088896340736f;  // softmax probabilities are rebuilt in base 2 (lse is stored * log2 e)
   const int g = lane >> 4;
   constexpr int ND = DH / 16;
   const int npair = Npad >> 5;
@@ -496,7 +499,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? HCT_BWD2_WPE : 2)) attn_bw
         const f32x4 D4 = *reinterpret_cast<const f32x4*>(sDel + q0 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = key_ok ? __expf(sacc[r] * scale - L4[r]) : 0.f;
+          const float pv = key_ok ? __builtin_amdgcn_exp2f(sacc[r] * scale2 - L4[r]) : 0.f;
           P[hh][r] = pv;
           dS[hh][r] = pv * (dp[r] - D4[r]) * scale;
         }
@@ -557,7 +560,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? HCT_BWD2_WPE : 2)) attn_bw
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = (k0 + 4 * g + r < N) ? __expf(sacc[r] * scale - Lq) : 0.f;
+          const float pv = (k0 + 4 * g + r < N) ? __builtin_amdgcn_exp2f(sacc[r] * scale2 - Lq) : 0.f;
           dS[hh][r] = pv * (dp[r] - Dq) * scale;
         }
       }
