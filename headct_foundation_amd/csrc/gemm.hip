@@ -625,13 +625,13 @@ __device__ uint32_t* g_stamp_ptr = nullptr;
 #endif
 
 // PERSISTENT: grid = min(tiles, #CUs); each workgroup walks tiles vb = blockIdx.x, +gridDim.x, ... (same XCD every trip,
-// consecutive tiles of an XCD share an A row-panel).  At the end of a tile the first three stages of the NEXT tile are
+// consecutive tiles of an XCD share an A row-panel).  At the end of a tile the first pair of stages of the NEXT tile is
 // issued before the epilogue, so the output stores (asynchronous) and the next tile's HBM latency drain under each other
 // and under the next main loop instead of leaving the CU's matrix pipes idle.
 template <int MODE>
 __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, int K, const bf16* __restrict__ A, int64_t lda,
                                                                  const bf16* __restrict__ B, int64_t ldb, Epilogue e, int ntiles, int stagger) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[163840];  // 4 stages x (A 16K | B 16K) + 32K epilogue
+  __shared__ __attribute__((aligned(16))) unsigned char smem[163840];  // 5 stages x (A 16K | B 16K); stages 3, 4 double as the epilogue patches
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ntm = (M + 255) >> 8, ntn = (N + 255) >> 8;
   float* const colsum_out = e.colsum_partial;  // by value: indexing through `e` made hipcc keep a copy of the struct in scratch
@@ -666,9 +666,16 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     ra = make_srd(Ab, clamp_records(((int64_t)(M - m0 - 1) * lda + K) * 2));
     rb = make_srd(Bb, clamp_records(((int64_t)(N - n0 - 1) * ldb + K) * 2));
   };
-  auto stage = [&](int t) {
-    const uint32_t base = lds0 + (t & 3) * 32768;  // wave-uniform by construction (wave is a readfirstlane result): SALU only
-    const uint32_t kb = (uint32_t)t * 64;          // 32 bf16 = 64 B per stage
+  // Stages are fetched in PAIRS (t even, t+1).  One stage is 32 bf16 = 64 B of every row, i.e. half a 128-B line, and a
+  // stream of half-line requests draws only 62 GB/s per CU from L2 where whole lines give 111 (scripts/micro/
+  // lds_dma_rate.hip); issuing the two halves of the same lines in consecutive instructions recovers most of it (94 GB/s
+  // per CU: the second request meets the line in the vector L1).  In the isolated GEMM benchmark (operands warm in the
+  // Infinity Cache) this schedule is 4 % slower than one stage per K-step on a ring of 4; inside the training step, where
+  // the operands come from HBM, it is 0.8 ms per step faster (scripts/ab_step.py) -- and it needs one barrier per two
+  // K-steps instead of two.
+  auto stage_pair = [&](int t) {
+    const uint32_t b0 = lds0 + (t % 5) * 32768, b1 = lds0 + ((t + 1) % 5) * 32768;  // wave-uniform: SALU only
+    const uint32_t kb = (uint32_t)t * 64;                                            // 32 bf16 = 64 B per stage
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = wave * 2 + i;
@@ -676,26 +683,29 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
       // per-stage VALU, nothing for the compiler to pre-compute and spill); rows past M are still dropped by the
       // descriptor's range check on voffset
 #ifdef HCT_TIMING_NO_DMA  // diagnostic build: main loop without its operand stream (outputs are garbage)
-      asm volatile("" ::"s"(base + c * 1024), "v"(voa[i]), "v"(vob[i]), "s"(kb), "s"(ra), "s"(rb));
+      asm volatile("" ::"s"(b0 + c * 1024), "s"(b1), "v"(voa[i]), "v"(vob[i]), "s"(kb), "s"(ra), "s"(rb));
 #else
-      dma16s(ra, base + c * 1024, voa[i], kb);
-      dma16s(rb, base + 16384 + c * 1024, vob[i], kb);
+      dma16s(ra, b0 + c * 1024, voa[i], kb);
+      dma16s(ra, b1 + c * 1024, voa[i], kb + 64);
+      dma16s(rb, b0 + 16384 + c * 1024, vob[i], kb);
+      dma16s(rb, b1 + 16384 + c * 1024, vob[i], kb + 64);
 #endif
     }
   };
   // Software pipeline at half-stage granularity (16 live fragments: 4 A + 4 A' + 4 B-low + 4 B-high):
   //   first half : issue the B-high reads of stage t, run the 16 MFMAs of columns 0..63 (B-low)
-  //   boundary   : stage t+1 landed (counted vmcnt + barrier), refill the ring, issue A' and B-low reads of stage t+1
+  //   boundary   : (odd stages only) the next pair has landed (vmcnt + barrier), refill the ring;
+  //                issue A' and B-low reads of stage t+1
   //   second half: run the 16 MFMAs of columns 64..127 (B-high) while those reads return
   f32x4 acc[4][8];
   bf16x8 b_lo[4], b_hi[4], a0[4], a1[4];
   auto rd_a = [&](int t, bf16x8* af) {
-    const unsigned char* sa = smem + (t & 3) * 32768 + wm * (64 * 64) + foff;
+    const unsigned char* sa = smem + (t % 5) * 32768 + wm * (64 * 64) + foff;
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 1024);
   };
   auto rd_b = [&](int t, int half, bf16x8* bq) {
-    const unsigned char* sb = smem + (t & 3) * 32768 + 16384 + wn * (128 * 64) + half * 4096 + foff;
+    const unsigned char* sb = smem + (t % 5) * 32768 + 16384 + wn * (128 * 64) + half * 4096 + foff;
 #pragma unroll
     for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const bf16x8*>(sb + j * 1024);
   };
@@ -708,11 +718,14 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
       for (int j = 0; j < 4; ++j)
         acc[i][half * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[i][half * 4 + j], 0, 0, 0);
   };
-  // stage landed: own DMA retired (leaving `later` younger stages in flight) + barrier
-  auto land = [&](int later) {
-    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // pair landed: this wave's DMA retired (all of it, or all but the 8 operations of the youngest pair) + barrier, after
+  // which every wave's pieces are visible
+  auto land_all = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  auto land_but_youngest_pair = [&]() {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
   // De-phase the persistent workgroups: all tiles cost the same, so without this every CU reaches its epilogue at the same
@@ -729,9 +742,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
 #endif
   int vb = blockIdx.x;
   set_tile(vb);
-  stage(0);
-  stage(1);
-  stage(2);
+  stage_pair(0);
   while (true) {
     HCT_STAMP(0);
     const int cm0 = m0, cn0 = n0;  // tile being computed (set_tile below moves m0/n0 to the next one)
@@ -739,49 +750,48 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    // nk is even and >= 4 (host dispatch: K % 64 == 0, K >= 128): steady-state loop without conditionals + static tail.
-    // The three prefetched stages are OLDER than the previous epilogue's loads and stores (vmcnt retires in issue order),
-    // so this vmcnt(8) also waits for all but the last 8 of those.  Counted waits that let the stores drain under the
-    // first MFMAs were tried and measured no gain: the epilogue is bound by store issue (~75 clk per wave-store), not drain.
-    land(2);
+    // nk is even and >= 4 (host dispatch: K % 64 == 0, K >= 128).  Ring of 5 stage buffers; pair (0,1) was issued before
+    // the previous tile's epilogue.  Buffers 3 and 4 were that epilogue's patches: once every wave is through with them
+    // (barrier) pair (2,3) may go.  Pair (0,1) is older than the epilogue's loads/stores and than pair (2,3) (vmcnt retires
+    // in issue order), so allowing the 8 youngest operations to be outstanding means (0,1) has landed.
+    __builtin_amdgcn_s_barrier();
+    stage_pair(2);
+    land_but_youngest_pair();
     HCT_STAMP(1);
     rd_a(0, a0);
     rd_b(0, 0, b_lo);
+    // Steady state, two K-steps per trip.  Even step t: no synchronisation at all (pair (t, t+1) became visible at the
+    // previous odd step).  Odd step t+1: pair (t+2, t+3), issued two steps ago, must have landed; every wave is then past
+    // its reads of stages t-1 and t, whose buffers take pair (t+4, t+5).
     int t = 0;
-    for (; t + 4 < nk; t += 2) {
+    for (; t + 5 < nk; t += 2) {
       rd_b(t, 1, b_hi);
       mma(0, a0, b_lo);
-      land(1);
-      stage(t + 3);
       rd_a(t + 1, a1);
       rd_b(t + 1, 0, b_lo);
       mma(1, a0, b_hi);
       rd_b(t + 1, 1, b_hi);
       mma(0, a1, b_lo);
-      land(1);
-      stage(t + 4);
+      land_all();
+      stage_pair(t + 4);
       rd_a(t + 2, a0);
       rd_b(t + 2, 0, b_lo);
       mma(1, a1, b_hi);
     }
-    // t == nk - 4
+    // t == nk - 4: every stage has been issued
     rd_b(t, 1, b_hi);
     mma(0, a0, b_lo);
-    land(1);
-    stage(t + 3);
     rd_a(t + 1, a1);
     rd_b(t + 1, 0, b_lo);
     mma(1, a0, b_hi);
     rd_b(t + 1, 1, b_hi);
     mma(0, a1, b_lo);
-    land(1);
+    land_all();  // pair (nk-2, nk-1)
     rd_a(t + 2, a0);
     rd_b(t + 2, 0, b_lo);
     mma(1, a1, b_hi);
-    // t == nk - 2
     rd_b(t + 2, 1, b_hi);
     mma(0, a0, b_lo);
-    land(0);
     rd_a(t + 3, a1);
     rd_b(t + 3, 0, b_lo);
     mma(1, a0, b_hi);
@@ -802,14 +812,12 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     }
     vb += gridDim.x;
     const bool more = vb < ntiles;
-    if (more) {  // prefetch the next tile's first three stages (ring buffers 0..2) under this tile's epilogue
+    if (more) {  // prefetch the next tile's first pair of stages (ring buffers 0, 1) under this tile's epilogue
       set_tile(vb);
-      stage(0);
-      stage(1);
-      stage(2);
+      stage_pair(0);
     }
     {
-      unsigned char* patch = smem + 3 * 32768 + wave * 8192;  // ring buffer 3 (+32K tail): untouched until the next land(1)
+      unsigned char* patch = smem + 3 * 32768 + wave * 8192;  // ring buffers 3 and 4: refilled only after the next tile's first barrier
       if (MODE == EPI_GENERIC) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) epilogue_tile16x128(e, patch, lane, cm0 + wm * 64 + i * 16, cn0 + wn * 128, M, N, acc[i]);
