@@ -1516,9 +1516,9 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
       const dim3 grid(std::min(tiles256, num_cus()));
       // one start phase = 1/8 of a tile's main loop (nk stages x ~1000 cycles; s_sleep(32) = 2048 cycles); only when each
       // CU runs several tiles (otherwise the delay is pure loss)
-      int stagger = 0;
-      if (g_stagger >= 0) stagger = g_stagger;
-      else if (tiles256 >= 3 * (int)grid.x) stagger = std::max(1, (a->K / 32) / 16);
+      // (a start-phase stagger of the workgroups helped the earlier one-stage-per-step schedule by ~0.1 ms per step; with
+      //  the paired schedule it is neutral to slightly negative: off unless forced through the debug hook)
+      const int stagger = g_stagger >= 0 ? g_stagger : 0;
 #define HCT_NT256(MODE_)                                                                                              \
   hipLaunchKernelGGL(gemm_bf16_nt256_kernel<MODE_>, grid, dim3(512), 0, s, a->M, a->N, a->K, (const bf16*)a->A, a->lda, \
                      (const bf16*)a->B, a->ldb, e, tiles256, stagger)
