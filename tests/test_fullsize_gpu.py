@@ -92,3 +92,26 @@ def test_full_depth_vitb_b4_vs_oracle(lib, cuda):
     assert rel_err(model.last_pred(B), o_pred) < 2e-2
     bad = [(rel_err(grads[k], o_grads[k]), k) for k in grads if not k.endswith("qkv.bias")]
     assert max(bad)[0] < 6e-2, sorted(bad)[-5:]
+
+
+def test_vitl_shapes_cut_depth_vs_oracle(lib, cuda):
+    """BASELINE config #4 geometry (ViT-L/16^3 on 128^3, learnable position table: D = 1024, 16 heads, 129 / 513 tokens,
+    MLP 4096) with the depth cut to 2 + 1 blocks so the oracle runs in seconds; bf16 tolerances as above."""
+    import dataclasses
+    cfg = dataclasses.replace(O.CONFIGS["vitl"], encoder_depth=2, decoder_depth=1)
+    B = 2
+    params = O.make_params(cfg, 9)
+    x, noise = O.make_volume(cfg, B, 9), O.make_noise(cfg, B, 9)
+    o_loss, o_pred, o_mask, o_grads, _ = O.forward_backward(cfg, params, x, noise)
+    model = build_hip_model(cfg, params, cuda, "bf16").train()
+    for p in model.parameters():
+        p.grad = None
+    loss, _, _ = model(x.to(cuda), noise=noise.to(cuda))
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = grads_by_name(model)
+    assert abs(float(loss.detach()) - float(o_loss)) / abs(float(o_loss)) < 5e-3
+    assert torch.equal(model.last_mask(B).cpu(), o_mask)
+    assert rel_err(model.last_pred(B), o_pred) < 2e-2
+    bad = [(rel_err(grads[k], o_grads[k]), k) for k in grads if not k.endswith("qkv.bias")]
+    assert max(bad)[0] < 6e-2, sorted(bad)[-5:]
