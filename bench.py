@@ -197,13 +197,14 @@ def main():
         raise SystemExit(f"non-finite loss during the benchmark: {lv.tolist()}")
 
     roof = None
+    traf = pmc_traffic()
     if prof:
         ms, n, w = C.c_double(), C.c_int64(), C.c_double()
         _lib.check(lib.hct_prof_read(0, C.byref(ms), C.byref(n), C.byref(w)), "hct_prof_read")
         if n.value and ms.value > 0:
             ach = w.value / (ms.value * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "gemm_bf16_nt256_kernel<*> (all epilogue modes)", "achieved": round(ach, 2),
-                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
+                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": (traf or {}).get("hbm_bytes_per_launch"), "traffic_detail": traf,
                     "algorithmic_TFLOP_per_launch": round(w.value / n.value / 1e12, 4),
                     "launches_per_step": n.value // max(1, (args.steps + 3) // 4), "sampled_steps": (args.steps + 3) // 4, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                     "time_share_of_step": round(ms.value * 1e-3 * args.steps / ((args.steps + 3) // 4) / elapsed, 4)}
