@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libheadct_hip.so")
 
 HCT_F32, HCT_BF16, HCT_F16 = 0, 1, 2
-HCT_ACT_NONE, HCT_ACT_GELU, HCT_ACT_DGELU = 0, 1, 2
+HCT_ACT_NONE, HCT_ACT_GELU, HCT_ACT_DGELU, HCT_ACT_TANH = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
 
 c_void_p, c_int, c_float, c_size_t, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
@@ -75,6 +75,10 @@ _PROTOS = {
     "hct_masked_mse": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hct_unpatchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "hct_vit_assemble_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "hct_channel_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "hct_query_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "hct_head_linear": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                c_int, c_void_p]),
     "hct_augment_volume": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "hct_pos_embed_interp3d": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "hct_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -4,8 +4,9 @@ Mirror of `ViT` (src/models/vit.py:26-173) for the downstream use of a pre-train
 parameter names (`cls_token`, `register_tokens`, `patch_embedding.*`, `blocks.N.*`, `norm.*`), `forward(x) -> (x,
 hidden_states_out)`: every patch embedded (+ position table), class token, register tokens, the blocks, final LayerNorm
 with eps 1e-6.  Built from the library's primitives (`hct_patch_gather`, `hct_gemm`, `hct_vit_assemble_fwd`,
-`hct_layernorm_fwd`, `hct_attention_fwd`); there is no autograd and no CPU path.  Not built: the classification head
-(`classification=True`), LoRA, 2-D inputs, the perceptron patch embedding.
+`hct_layernorm_fwd`, `hct_attention_fwd`, `hct_head_linear`); there is no autograd and no CPU path.  With
+`classification=True` the class-token head of vit.py:133-137 / :170-171 (Linear, Tanh unless `post_activation` says
+otherwise) is applied and `forward` returns the class scores.  Not built: LoRA, 2-D inputs, the perceptron patch embedding.
 """
 from __future__ import annotations
 
@@ -30,9 +31,8 @@ class ViT(nn.Module):
             raise ValueError("dropout_rate should be between 0 and 1.")
         if hidden_size % num_heads != 0:
             raise ValueError("hidden_size should be divisible by num_heads.")
-        if classification or lora or spatial_dims != 3 or patch_embed != "conv" or dropout_rate != 0.0 or norm_layer is not nn.LayerNorm:
-            raise NotImplementedError("HIP ViT: feature extraction only (classification=False, lora=False, 3-D conv patch "
-                                      "embedding, dropout 0, nn.LayerNorm)")
+        if lora or spatial_dims != 3 or patch_embed != "conv" or dropout_rate != 0.0 or norm_layer is not nn.LayerNorm:
+            raise NotImplementedError("HIP ViT: forward only (lora=False, 3-D conv patch embedding, dropout 0, nn.LayerNorm)")
         if pos_embed not in ("learnable", "sincos", "none"):
             raise ValueError(f"pos_embed type {pos_embed} not supported.")
         if compute_dtype not in ("bf16", "fp32"):
@@ -58,6 +58,11 @@ class ViT(nn.Module):
         self.cls_token = nn.Parameter(torch.zeros(1, 1, D))
         self.norm = _Affine(D, bias_shape=(D,))
         self.register_tokens = nn.Parameter(torch.zeros(1, num_register_tokens, D)) if num_register_tokens else None
+        self.classification = classification
+        self.post_activation = post_activation
+        if classification:  # vit.py:133-137: Sequential(Linear, Tanh) -> keys `classification_head.0.*`, else a bare Linear
+            head = _Affine(num_classes, D, bias_shape=(num_classes,))
+            self.classification_head = nn.Sequential(head) if post_activation == "Tanh" else head
         with torch.no_grad():  # reference init: patch_embedding.py:112-130, nn.Linear / nn.LayerNorm defaults, vit.py:139-142
             if pos_embed == "learnable":
                 nn.init.trunc_normal_(self.patch_embedding.position_embeddings, mean=0.0, std=0.02, a=-2.0, b=2.0)
@@ -68,6 +73,8 @@ class ViT(nn.Module):
                 m.bias.zero_()
             import math
             lin = [pe_ for pe_ in [self.patch_embedding.patch_embeddings]]
+            if classification:
+                lin.append(self.classification_head[0] if post_activation == "Tanh" else self.classification_head)
             for b_ in self.blocks:
                 lin += [b_.attn.qkv, b_.attn.proj, b_.mlp.linear1, b_.mlp.linear2]
             for m in lin:  # nn.Linear / nn.Conv3d defaults (the reference's ViT has no custom weight init)
@@ -177,4 +184,13 @@ class ViT(nn.Module):
                 h = self._linear(g, self._weight(blk.mlp.linear2.weight), blk.mlp.linear2.bias, torch.float32, residual=h_mid)
                 hidden.append(h.view(B, T, D))
             out = self._layernorm(h, self.norm, 1e-6, torch.float32).view(B, T, D)
+            if self.classification:  # classification_head(x[:, 0]), vit.py:170-171
+                tanh = self.post_activation == "Tanh"
+                head = self.classification_head[0] if tanh else self.classification_head
+                ncls = head.weight.shape[0]
+                scores = torch.empty(B, ncls, dtype=torch.float32, device=dev)
+                _lib.check(self._lib.hct_head_linear(out.data_ptr(), T * D, 1, None, None, 0.0, head.weight.data_ptr(), head.bias.data_ptr(),
+                                                     _lib.HCT_ACT_TANH if tanh else _lib.HCT_ACT_NONE, scores.data_ptr(), B, D, ncls,
+                                                     self._st), "hct_head_linear")
+                out = scores
         return out, hidden

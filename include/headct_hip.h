@@ -38,6 +38,7 @@ extern "C" {
 #define HCT_ACT_NONE 0
 #define HCT_ACT_GELU 1  /* out = gelu_erf(acc + bias); aux (if given) receives the pre-activation */
 #define HCT_ACT_DGELU 2 /* out = acc * gelu_erf'(aux)   (aux = saved pre-activation)             */
+#define HCT_ACT_TANH 3  /* hct_head_linear only: out = tanh(acc + bias)                           */
 
 const char* hct_last_error_string(void);
 int hct_version(void);
@@ -167,6 +168,27 @@ int hct_unpatchify(const void* pred, int pred_dtype, int has_cls_row, int B, int
  *   h[b,0,:] = cls;  h[b,1+r,:] = reg[r,:] (r < R);  h[b,1+R+l,:] = tok[b*L+l,:] + pos[l,:]        (pos / reg may be NULL) */
 int hct_vit_assemble_fwd(const void* tok, int tok_dtype, const float* cls, const float* reg, const float* pos, int B,
                          int L, int R, int D, float* h, void* stream);
+
+/* Classification heads over the ViT features, forward / eval-mode arithmetic (src/models/classifier.py:7-99 and the
+ * `classification_head` of src/models/vit.py:133-137, :170-171).  All fp32 unless a dtype is given.
+ *
+ * hct_channel_norm: nn.BatchNorm1d(C, affine=False) in eval mode on [rows, C] (classifier.py:89 `bn1`):
+ *   out[r, c] = (x[r, c] - mean[c]) / sqrt(var[c] + eps)                                   C % 4 == 0
+ * hct_query_attention: the learnt queries of AttentionClassifier against every token (classifier.py:84-93):
+ *   out[b, h, q, :] = softmax_n(logit_scale * <q[q, h*dh:(h+1)*dh], K[b, n, h, :]>) @ V[b, :, h, :]
+ *   q: [Q, H*dh] fp32 (the raw `cls_token`; the reference scales it by `scale` and SDPA by dh^-1/2 again, so the caller
+ *   passes logit_scale = scale * dh^-1/2); kv: [B, N, 2, H, dh] (the `wkv` output as it lies, classifier.py:90);
+ *   out: [B, H, Q, dh] fp32 - the layout classifier.py:95 reshapes WITHOUT a permute.  Q*N + 4*Q*dh + Q <= 16384.
+ * hct_head_linear: an optional eval-mode BatchNorm1d, the mean over nq consecutive D-vectors, a Linear and an optional Tanh:
+ *   out[r, c] = act( sum_k (1/nq * sum_q (x[r*ldx + q*D + k] - mean[k]) / sqrt(var[k] + eps)) * W[c, k] + bias[c] )
+ *   mean = var = NULL skips the normalisation; act = HCT_ACT_NONE | HCT_ACT_TANH.  (LinearClassifier: nq = 1, ldx = D;
+ *   AttentionClassifier's bn2 + mean + linear: nq = Q, ldx = Q*D; ViT classification_head on x[:, 0]: ldx = T*D.) */
+int hct_channel_norm(const float* x, const float* mean, const float* var, float eps, void* out, int out_dtype, int64_t rows,
+                     int C, void* stream);
+int hct_query_attention(const float* q, int Q, const void* kv, int kv_dtype, int B, int N, int H, int dh, float logit_scale,
+                        float* out, void* stream);
+int hct_head_linear(const float* x, int64_t ldx, int nq, const float* mean, const float* var, float eps, const float* W,
+                    const float* bias, int act, float* out, int rows, int D, int n_out, void* stream);
 
 /* Device side of the reference's per-sample MAE input transforms, mae3d_transforms(mode='train'), src/data/transforms.py:
  * 193-228: CastToTyped(float32) of the cached volume (fp16 on disk, transforms.py:170-175) -> RandFlipd on spatial axes

@@ -391,23 +391,29 @@ def forward(cfg: MAEConfig, p: Dict[str, torch.Tensor], x: torch.Tensor, noise: 
 
 def make_vit_params(shapes: Dict[str, Sequence[int]], seed0: int = 100) -> Dict[str, torch.Tensor]:
     """Deterministic non-trivial values for a ViT state dict (fixtures): hash stream i per tensor in sorted key order,
-    x0.02 for matrices, x0.1 for vectors, +1 on LayerNorm weights."""
+    x0.02 for matrices, x0.1 for vectors, +1 on LayerNorm weights; BatchNorm buffers of the classifier heads:
+    running_var = 0.5 + |u|, num_batches_tracked = 0."""
     out = {}
     for i, n in enumerate(sorted(shapes)):
         shp = tuple(int(v) for v in shapes[n])
+        if n.endswith("num_batches_tracked"):
+            out[n] = torch.zeros(shp, dtype=torch.int64)
+            continue
         numel = int(np.prod(shp))
         scale = 0.02 if len(shp) > 1 else 0.1
         t = torch.from_numpy(hash_uniform(numel, seed0 + i).reshape(shp).astype(np.float32)) * scale
         if n.endswith("norm.weight"):
             t = t + 1.0
+        if n.endswith("running_var"):
+            t = 0.5 + (t / scale).abs()
         out[n] = t
     return out
 
 
 def vit_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, patch_size: int, num_heads: int, num_layers: int):
-    """ViT.forward without a classification head, src/models/vit.py:144-173: embed EVERY patch (+ position table), prepend
-    the class token, insert the register tokens behind it (:150-160), run the blocks collecting each output, final
-    LayerNorm with eps 1e-6 (:124).  Returns (x, hidden_states_out)."""
+    """ViT.forward, src/models/vit.py:144-173: embed EVERY patch (+ position table), prepend the class token, insert the
+    register tokens behind it (:150-160), run the blocks collecting each output, final LayerNorm with eps 1e-6 (:124) and,
+    when the state dict holds a `classification_head`, that head on the class token.  Returns (x, hidden_states_out)."""
     B = x.shape[0]
     tok = F.conv3d(x, p["patch_embedding.patch_embeddings.weight"], p["patch_embedding.patch_embeddings.bias"], stride=patch_size)
     tok = tok.flatten(2).transpose(-1, -2)
@@ -421,7 +427,44 @@ def vit_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, patch_size: int, nu
         h = _block(p, f"blocks.{i}", h, num_heads, None, "")
         hidden.append(h)
     out = F.layer_norm(h, (h.shape[-1],), p["norm.weight"], p["norm.bias"], 1e-6)
+    if "classification_head.0.weight" in p:  # nn.Sequential(Linear, Tanh) on the class token, vit.py:133-135, :170-171
+        out = torch.tanh(out[:, 0] @ p["classification_head.0.weight"].T + p["classification_head.0.bias"])
+    elif "classification_head.weight" in p:  # post_activation != "Tanh", vit.py:136-137
+        out = out[:, 0] @ p["classification_head.weight"].T + p["classification_head.bias"]
     return out, hidden
+
+
+def batchnorm1d_eval(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """nn.BatchNorm1d(dim, affine=False, eps=1e-6) in eval mode (classifier.py:18, :65-66), channels on the LAST axis here
+    (the reference transposes to put them on axis 1 and back, classifier.py:89, :96)."""
+    return (x - mean) / torch.sqrt(var + eps)
+
+
+def linear_classifier_forward(p: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
+    """LinearClassifier.forward, classifier.py:21-33 (eval): bn -> linear.  x: [B, dim]."""
+    x = batchnorm1d_eval(x, p["bn.running_mean"], p["bn.running_var"])
+    return x @ p["linear.weight"].T + p["linear.bias"]
+
+
+def attention_classifier_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, num_heads: int, num_queries: int,
+                                 qk_scale: Optional[float] = None) -> torch.Tensor:
+    """AttentionClassifier.forward, classifier.py:73-99 (eval).  x: [B, N, C] token features.  The learnt queries are scaled
+    by `scale` (:86) and F.scaled_dot_product_attention scales the logits by dh^-1/2 once more (:93); its output
+    [B, H, Q, dh] is reshaped to [B, Q, C] without a permute (:95)."""
+    B, N, C = x.shape
+    dh = C // num_heads
+    scale = qk_scale or dh ** -0.5
+    q = p["cls_token"].expand(B, -1, -1).reshape(B, num_queries, num_heads, dh).permute(0, 2, 1, 3) * scale
+    x = batchnorm1d_eval(x, p["bn1.running_mean"], p["bn1.running_var"])
+    kv = x @ p["wkv.weight"].T
+    if "wkv.bias" in p:
+        kv = kv + p["wkv.bias"]
+    kv = kv.reshape(B, N, 2, num_heads, dh).permute(2, 0, 3, 1, 4)
+    k, v = kv[0], kv[1]
+    att = torch.softmax((q @ k.transpose(-1, -2)) * dh ** -0.5, dim=-1)
+    x_cls = (att @ v).reshape(B, num_queries, C)
+    x_cls = batchnorm1d_eval(x_cls, p["bn2.running_mean"], p["bn2.running_var"]).mean(dim=1)
+    return x_cls @ p["linear.weight"].T + p["linear.bias"]
 
 
 def forward_backward(cfg: MAEConfig, params: Dict[str, torch.Tensor], x: torch.Tensor, noise: torch.Tensor,

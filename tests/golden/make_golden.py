@@ -304,6 +304,59 @@ def vit_fixture():
         json.dump(fx, f)
 
 
+def classifier_fixture():
+    """Eval-mode LinearClassifier / AttentionClassifier (src/models/classifier.py) and ViT(classification=True); full outputs."""
+    from src.models.classifier import AttentionClassifier, LinearClassifier
+    from src.models.vit import ViT
+    fx = {}
+    # LinearClassifier
+    ref = LinearClassifier(192, 3).eval()
+    params = O.make_vit_params({k: list(v.shape) for k, v in ref.state_dict().items()}, seed0=300)
+    ref.load_state_dict(params, strict=True)
+    x = torch.from_numpy(O.hash_uniform(5 * 192, 31).reshape(5, 192).astype(np.float32))
+    with torch.no_grad():
+        out = ref(x)
+    err = float((out - O.linear_classifier_forward(params, x)).abs().max())
+    assert out.shape == (5, 3) and err < 2e-6, err
+    fx["linear"] = dict(ctor=dict(dim=192, num_classes=3), seed0=300, x_seed=31, x_shape=[5, 192], max_abs_dev_oracle=err,
+                        state_dict={k: dict(shape=list(v.shape)) for k, v in ref.state_dict().items()}, out=out.flatten().tolist())
+    # AttentionClassifier, one and several learnt queries
+    for name, nq, bias, seed0 in (("attention_q1", 1, False, 320), ("attention_q3", 3, True, 340)):
+        kw = dict(dim=192, num_classes=4, num_heads=3, qkv_bias=bias, num_queries=nq)
+        ref = AttentionClassifier(**kw).eval()
+        params = O.make_vit_params({k: list(v.shape) for k, v in ref.state_dict().items()}, seed0=seed0)
+        params["cls_token"] = params["cls_token"] * 50.0  # logits of order one, so that the softmax is not flat
+        ref.load_state_dict(params, strict=True)
+        x = torch.from_numpy(O.hash_uniform(2 * 11 * 192, 33).reshape(2, 11, 192).astype(np.float32)) * 2.0
+        with torch.no_grad():
+            out = ref(x)
+        err = float((out - O.attention_classifier_forward(params, x, 3, nq)).abs().max())
+        assert out.shape == (2, 4) and err < 2e-6, (name, err)
+        fx[name] = dict(ctor=kw, seed0=seed0, cls_token_gain=50.0, x_seed=33, x_shape=[2, 11, 192], x_gain=2.0, max_abs_dev_oracle=err,
+                        state_dict={k: dict(shape=list(v.shape)) for k, v in ref.state_dict().items()}, out=out.flatten().tolist())
+    # ViT with its own classification head (Linear + Tanh, and plain Linear)
+    for name, post in (("vit_tanh", "Tanh"), ("vit_linear", "none")):
+        kw = dict(in_chans=1, img_size=(32, 32, 32), patch_size=(16, 16, 16), hidden_size=192, mlp_dim=384, num_layers=2, num_heads=3,
+                  patch_embed="conv", pos_embed="learnable", classification=True, num_classes=3, post_activation=post,
+                  num_register_tokens=1, qkv_bias=True)
+        ref = ViT(**kw).eval()
+        params = O.make_vit_params({k: list(v.shape) for k, v in ref.state_dict().items()}, seed0=360)
+        for k in params:
+            if k.startswith("classification_head") and k.endswith("weight"):
+                params[k] = params[k] * 10.0  # class scores of order one
+        ref.load_state_dict(params, strict=True)
+        x = torch.from_numpy(O.hash_uniform(2 * 32 ** 3, 7).reshape(2, 1, 32, 32, 32).astype(np.float32)) * 0.5 + 0.5
+        with torch.no_grad():
+            out, hidden = ref(x)
+        o_out, _ = O.vit_forward(params, x, 16, 3, 2)
+        err = float((out - o_out).abs().max())
+        assert out.shape == (2, 3) and err < 5e-6, (name, err)
+        fx[name] = dict(ctor=dict(kw, img_size=32, patch_size=16), seed0=360, head_weight_gain=10.0, max_abs_dev_oracle=err,
+                        state_dict={k: dict(shape=list(v.shape)) for k, v in ref.state_dict().items()}, out=out.flatten().tolist())
+    with open(os.path.join(HERE, "classifier_heads.json"), "w") as f:
+        json.dump(fx, f)
+
+
 def pos_interp_fixture():
     """interpolate_pos_embed (pos_embed.py:102-153) on a learnable table, up- and down-sampling; full outputs (small)."""
     from src.utils.pos_embed import interpolate_pos_embed
@@ -334,6 +387,7 @@ if __name__ == "__main__":
     lr_schedule_fixture()
     pos_interp_fixture()
     vit_fixture()
+    classifier_fixture()
     run_case("micro", 2, 0, full=True)
     run_case("yaml_cut", 2, 1, full=False)
     run_case("tiny", 2, 0, full=False)

@@ -147,3 +147,45 @@ def test_vit_feature_extraction_vs_oracle_and_reference_fixture(lib, cuda, dtype
         for t, entry in [(out, fx["out"])] + list(zip(hidden, fx["hidden"])):
             got, want, l2, l2w = sample_of(t, entry)
             assert torch.allclose(got, want, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["linear", "attention_q1", "attention_q3", "vit_tanh", "vit_linear"])
+def test_classifier_heads_vs_oracle_and_reference_fixture(lib, cuda, name):
+    """HIP LinearClassifier / AttentionClassifier (eval arithmetic) and ViT(classification=True) vs the oracle and the
+    outputs of the reference's own modules (tests/golden/classifier_heads.json).  fp32 path: rel 1e-3 (observed ~1e-6)."""
+    import json, os
+    from headct_foundation_amd import AttentionClassifier, LinearClassifier, ViT
+    from tests.test_oracle_golden import _head_inputs, _head_oracle
+    e = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "classifier_heads.json")))[name]
+    params, x = _head_inputs(name, e)
+    want = _head_oracle(name, e, params, x)
+    if name == "linear":
+        model = LinearClassifier(**e["ctor"])
+    elif name.startswith("attention"):
+        model = AttentionClassifier(**e["ctor"])
+    else:
+        model = ViT(**e["ctor"], compute_dtype="fp32")
+    model.load_state_dict(params, strict=True)
+    model = model.to(cuda).eval()
+    out = model(x.to(cuda))
+    out = out[0] if isinstance(out, tuple) else out
+    assert out.shape == want.shape and rel_err(out, want) < 1e-3
+    assert torch.allclose(out.cpu(), torch.tensor(e["out"]).reshape(want.shape), rtol=1e-3, atol=1e-5)
+
+
+def test_attention_classifier_bf16_full_width(lib, cuda):
+    """AttentionClassifier at ViT-B width on 217 tokens, bf16 key/value projection (MFMA GEMM) vs the oracle: 2e-2."""
+    from headct_foundation_amd import AttentionClassifier
+    torch.manual_seed(5)
+    m = AttentionClassifier(768, 5, num_heads=12, qkv_bias=True, num_queries=4, compute_dtype="bf16")
+    with torch.no_grad():
+        m.cls_token.mul_(40.0)
+        m.bn1.running_mean.normal_(0, 0.2)
+        m.bn1.running_var.uniform_(0.5, 1.5)
+        m.bn2.running_mean.normal_(0, 0.05)
+        m.bn2.running_var.uniform_(0.05, 0.2)
+    params = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(6, 217, 768)
+    want = O.attention_classifier_forward(params, x, 12, 4)
+    out = m.to(cuda).eval()(x.to(cuda))
+    assert rel_err(out, want) < 2e-2

@@ -128,3 +128,64 @@ def test_vit_feature_extraction_against_reference_fixture():
     for t, entry in [(out, fx["out"])] + list(zip(hidden, fx["hidden"])):
         got, want, l2, l2w = sample_of(t, entry)
         assert torch.allclose(got, want, rtol=0, atol=5e-6) and abs(l2 - l2w) < 1e-4 * l2w
+
+
+def _head_inputs(name, e):
+    """Parameters and input of one entry of tests/golden/classifier_heads.json, rebuilt from their seeds."""
+    import numpy as np
+    import torch
+    from oracle import mae_oracle as O
+    params = O.make_vit_params({k: v["shape"] for k, v in e["state_dict"].items()}, seed0=e["seed0"])
+    if name.startswith("attention"):
+        params["cls_token"] = params["cls_token"] * e["cls_token_gain"]
+        shp = e["x_shape"]
+        x = torch.from_numpy(O.hash_uniform(int(np.prod(shp)), e["x_seed"]).reshape(shp).astype(np.float32)) * e["x_gain"]
+    elif name == "linear":
+        shp = e["x_shape"]
+        x = torch.from_numpy(O.hash_uniform(int(np.prod(shp)), e["x_seed"]).reshape(shp).astype(np.float32))
+    else:
+        for k in params:
+            if k.startswith("classification_head") and k.endswith("weight"):
+                params[k] = params[k] * e["head_weight_gain"]
+        x = torch.from_numpy(O.hash_uniform(2 * 32 ** 3, 7).reshape(2, 1, 32, 32, 32).astype(np.float32)) * 0.5 + 0.5
+    return params, x
+
+
+def _head_oracle(name, e, params, x):
+    from oracle import mae_oracle as O
+    if name == "linear":
+        return O.linear_classifier_forward(params, x)
+    if name.startswith("attention"):
+        return O.attention_classifier_forward(params, x, e["ctor"]["num_heads"], e["ctor"]["num_queries"])
+    return O.vit_forward(params, x, 16, 3, 2)[0]
+
+
+def test_classifier_heads_oracle_matches_reference_fixture():
+    """LinearClassifier / AttentionClassifier (eval) and ViT(classification=True): the oracle against outputs of the
+    reference's own modules (tests/golden/make_golden.py: classifier_fixture)."""
+    import torch
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "classifier_heads.json")))
+    assert set(fx) == {"linear", "attention_q1", "attention_q3", "vit_tanh", "vit_linear"}
+    for name, e in fx.items():
+        params, x = _head_inputs(name, e)
+        out = _head_oracle(name, e, params, x)
+        want = torch.tensor(e["out"]).reshape(out.shape)
+        assert torch.allclose(out, want, rtol=0, atol=5e-6), name
+
+
+def test_classifier_modules_mirror_reference_state_dict():
+    """Host mirrors register the reference's parameter / buffer names in the reference's order (no GPU needed)."""
+    from headct_foundation_amd import AttentionClassifier, LinearClassifier, ViT
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "classifier_heads.json")))
+    for name, e in fx.items():
+        cls = LinearClassifier if name == "linear" else AttentionClassifier if name.startswith("attention") else ViT
+        m = cls(**e["ctor"])
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(e["state_dict"].keys()), name
+        assert all(list(sd[k].shape) == v["shape"] for k, v in e["state_dict"].items()), name
+    import pytest
+    import torch
+    with pytest.raises(Exception, match="eval"):
+        LinearClassifier(8, 2)(torch.zeros(1, 8))
+    with pytest.raises(Exception, match="GPU"):
+        LinearClassifier(8, 2).eval()(torch.zeros(1, 8))
