@@ -3,4 +3,4 @@ from .mae import MaskedAutoencoderViT, build_sincos_position_embedding  # noqa: 
 from ._lib import HctError  # noqa: F401
 from .pos_embed import interpolate_pos_embed  # noqa: F401
 from .vit import ViT  # noqa: F401
-from .classifier import AttentionClassifier, LinearClassifier  # noqa: F401
+from .classifier import AttentionClassifier, LinearClassifier, cross_entropy  # noqa: F401

@@ -3,8 +3,11 @@
 Mirrors of `LinearClassifier` and `AttentionClassifier` (src/models/classifier.py:7-99): same constructor arguments,
 parameter and buffer names (`bn.running_mean`, `bn.running_var`, `bn.num_batches_tracked`, `linear.*`; `bn1`, `bn2`, `wkv.*`,
 `cls_token`), so a head trained with the reference loads with `load_state_dict`.  The BatchNorm layers use their running
-statistics - what the reference computes after `.eval()`; the training-mode batch statistics (and any backward) are not
-built, so `forward` refuses a module left in training mode.  There is no CPU path.
+statistics - what the reference computes after `.eval()`.  `LinearClassifier` also runs in training mode on frozen
+(detached) features - linear probing, engine_downstream.py:70-117 with TRAIN.LOCK: batch statistics + running-statistics
+update, logits, `cross_entropy` (nn.CrossEntropyLoss()) and the gradients of `linear.weight` / `linear.bias`, all on the HIP
+kernels through `torch.autograd.Function`s.  Not built: gradients with respect to the features (fine-tuning the backbone)
+and the training mode of `AttentionClassifier`, whose `forward` refuses a module left in training mode.  No CPU path.
 """
 from __future__ import annotations
 
@@ -37,12 +40,86 @@ def _init_linear(m: _Affine) -> None:  # nn.Linear defaults
         nn.init.uniform_(m.bias, -bound, bound)
 
 
-def _require_eval_cuda(mod: nn.Module, x: torch.Tensor, what: str) -> None:
-    if mod.training:
+def _require_eval_cuda(mod: nn.Module, x: torch.Tensor, what: str, need_eval: bool = True) -> None:
+    if mod.training and need_eval:
         raise _lib.HctError(f"{what} (HIP) computes the eval-mode forward (BatchNorm running statistics): call .eval() first; "
                             "training-mode batch statistics are not built")
     if not x.is_cuda or not mod.linear.weight.is_cuda:
         raise _lib.HctError(f"{what} (HIP) runs on the GPU: move the module and the input to 'cuda' (no CPU fallback exists)")
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _LinearProbeFn(torch.autograd.Function):
+    """Training-mode LinearClassifier on detached features: BatchNorm1d batch statistics (+ running update, momentum 0.1),
+    Linear; backward gives the parameter gradients only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn):
+        lib = _lib.load()
+        B, D = x.shape
+        ncls = weight.shape[0]
+        with torch.cuda.device(x.device):
+            st = _stream(x.device)
+            mean = torch.empty(D, dtype=torch.float32, device=x.device)
+            var = torch.empty(D, dtype=torch.float32, device=x.device)
+            _lib.check(lib.hct_batchnorm_stats(x.data_ptr(), B, D, 0.1, mean.data_ptr(), var.data_ptr(), bn.running_mean.data_ptr(),
+                                               bn.running_var.data_ptr(), st), "hct_batchnorm_stats")
+            bn.num_batches_tracked += 1
+            out = torch.empty(B, ncls, dtype=torch.float32, device=x.device)
+            _lib.check(lib.hct_head_linear(x.data_ptr(), D, 1, mean.data_ptr(), var.data_ptr(), bn.eps, weight.data_ptr(), bias.data_ptr(),
+                                           _lib.HCT_ACT_NONE, out.data_ptr(), B, D, ncls, st), "hct_head_linear")
+        ctx.save_for_backward(x, mean, var)
+        ctx.eps, ctx.ncls = bn.eps, ncls
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        x, mean, var = ctx.saved_tensors
+        lib = _lib.load()
+        B, D = x.shape
+        dlogits = dlogits.to(torch.float32).contiguous()
+        with torch.cuda.device(x.device):
+            dW = torch.empty(ctx.ncls, D, dtype=torch.float32, device=x.device)
+            db = torch.empty(ctx.ncls, dtype=torch.float32, device=x.device)
+            _lib.check(lib.hct_head_linear_wgrad(x.data_ptr(), mean.data_ptr(), var.data_ptr(), ctx.eps, dlogits.data_ptr(), B, D, ctx.ncls,
+                                                 dW.data_ptr(), db.data_ptr(), _stream(x.device)), "hct_head_linear_wgrad")
+        return None, dW, db, None
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        lib = _lib.load()
+        B, ncls = logits.shape
+        with torch.cuda.device(logits.device):
+            loss = torch.empty((), dtype=torch.float32, device=logits.device)
+            _lib.check(lib.hct_softmax_xent(logits.data_ptr(), target.data_ptr(), B, ncls, None, loss.data_ptr(), None, _stream(logits.device)),
+                       "hct_softmax_xent")
+        ctx.save_for_backward(logits, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, target = ctx.saved_tensors
+        lib = _lib.load()
+        B, ncls = logits.shape
+        dloss = dloss.to(torch.float32).contiguous()
+        with torch.cuda.device(logits.device):
+            dlogits = torch.empty_like(logits)
+            _lib.check(lib.hct_softmax_xent(logits.data_ptr(), target.data_ptr(), B, ncls, dloss.data_ptr(), None, dlogits.data_ptr(),
+                                            _stream(logits.device)), "hct_softmax_xent")
+        return dlogits, None
+
+
+def cross_entropy(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """nn.CrossEntropyLoss() of main_downstream.py:214 (mean reduction, class-index targets, no weights) on the HIP kernel.
+    A target outside [0, num_classes) makes the loss NaN (the reference's loop stops on a non-finite loss)."""
+    if not logits.is_cuda or logits.dim() != 2 or target.shape != logits.shape[:1]:
+        raise _lib.HctError("cross_entropy (HIP): logits [B, C] on 'cuda' and class-index targets [B] expected (no CPU fallback exists)")
+    return _CrossEntropyFn.apply(logits.to(torch.float32).contiguous(), target.to(device=logits.device, dtype=torch.int64).contiguous())
 
 
 class LinearClassifier(nn.Module):
@@ -55,14 +132,18 @@ class LinearClassifier(nn.Module):
         with torch.no_grad():
             _init_linear(self.linear)
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        _require_eval_cuda(self, x, "LinearClassifier")
+        _require_eval_cuda(self, x, "LinearClassifier", need_eval=False)
         ncls, dim = self.linear.weight.shape
         if x.dim() != 2 or x.shape[1] != dim:
             raise _lib.HctError(f"input shape {tuple(x.shape)} != (B, {dim})")
+        if self.training:  # linear probing on frozen features
+            if x.requires_grad:
+                raise _lib.HctError("LinearClassifier (HIP) trains on detached features (TRAIN.LOCK): the gradient with respect to "
+                                    "the features is not built")
+            return _LinearProbeFn.apply(x.to(torch.float32).contiguous(), self.linear.weight, self.linear.bias, self.bn)
         lib = _lib.load()
-        with torch.cuda.device(x.device):
+        with torch.no_grad(), torch.cuda.device(x.device):
             st = torch.cuda.current_stream().cuda_stream
             x = x.to(torch.float32).contiguous()
             out = torch.empty(x.shape[0], ncls, dtype=torch.float32, device=x.device)

@@ -97,9 +97,114 @@ __global__ void __launch_bounds__(256) head_linear_kernel(const float* __restric
   }
 }
 
+// ---- linear probing (LinearClassifier in training mode on frozen features, engine_downstream.py:70-117) ----------------
+
+// nn.BatchNorm1d training statistics over the batch axis of [B, D]: mean, biased variance (used to normalise) and the
+// running-statistics update with the unbiased variance (momentum 0.1).  One thread per channel, rows in index order.
+__global__ void __launch_bounds__(256) batch_stats_kernel(const float* __restrict__ x, int B, int D, float momentum,
+                                                          float* __restrict__ mean, float* __restrict__ var,
+                                                          float* __restrict__ rmean, float* __restrict__ rvar) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= D) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += x[(size_t)b * D + k];
+  const float m = s / (float)B;
+  float q = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float d = x[(size_t)b * D + k] - m;
+    q = fmaf(d, d, q);
+  }
+  mean[k] = m;
+  var[k] = q / (float)B;
+  if (rmean) {
+    rmean[k] = (1.0f - momentum) * rmean[k] + momentum * m;
+    rvar[k] = (1.0f - momentum) * rvar[k] + momentum * (q / (float)(B - 1));
+  }
+}
+
+// nn.CrossEntropyLoss() (mean reduction, class-index targets): loss = mean_b( logsumexp(l_b) - l_b[t_b] ),
+// dlogits[b, c] = (softmax(l_b)[c] - [c == t_b]) * dloss / B.  One workgroup; rows folded in a fixed order.
+__global__ void __launch_bounds__(256) softmax_xent_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, int B,
+                                                           int Cn, const float* __restrict__ dloss, float* __restrict__ loss,
+                                                           float* __restrict__ dlogits) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  const float g = (dloss ? dloss[0] : 1.0f) / (float)B;
+  float acc = 0.f;
+  for (int b = tid; b < B; b += 256) {
+    const float* l = logits + (size_t)b * Cn;
+    const int t = (int)target[b];
+    float m = -INFINITY;
+    for (int c = 0; c < Cn; ++c) m = fmaxf(m, l[c]);
+    float z = 0.f;
+    for (int c = 0; c < Cn; ++c) z += expf(l[c] - m);
+    acc += (logf(z) + m) - (t >= 0 && t < Cn ? l[t] : NAN);  // a target outside [0, C) poisons the loss instead of reading out of bounds
+    if (dlogits) {
+      const float iz = 1.0f / z;
+      for (int c = 0; c < Cn; ++c) dlogits[(size_t)b * Cn + c] = (expf(l[c] - m) * iz - (c == t ? 1.0f : 0.0f)) * g;
+    }
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0 && loss) loss[0] = red[0] / (float)B;
+}
+
+// parameter gradients of Linear(BatchNorm(x)):  dW[c, k] = sum_b dl[b, c] * (x[b, k] - mean[k]) / sqrt(var[k] + eps),
+// db[c] = sum_b dl[b, c];  one thread per (c, k), rows in index order.
+__global__ void __launch_bounds__(256) head_linear_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                                const float* __restrict__ var, float eps,
+                                                                const float* __restrict__ dl, int B, int D, int Cn,
+                                                                float* __restrict__ dW, float* __restrict__ db) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)Cn * D) return;
+  const int c = (int)(i / D), k = (int)(i - (int64_t)c * D);
+  const float m = mean ? mean[k] : 0.f, is = mean ? 1.0f / sqrtf(var[k] + eps) : 1.0f;
+  float acc = 0.f, bs = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float d = dl[(size_t)b * Cn + c];
+    acc = fmaf(d, (x[(size_t)b * D + k] - m) * is, acc);
+    bs += d;
+  }
+  dW[i] = acc;
+  if (k == 0 && db) db[c] = bs;
+}
+
 }  // namespace hct
 
 extern "C" {
+
+int hct_batchnorm_stats(const float* x, int B, int D, float momentum, float* mean, float* var, float* running_mean,
+                        float* running_var, void* stream) {
+  HCT_REQUIRE(x && mean && var && B > 1 && D > 0 && (!running_mean == !running_var),
+              "hct_batchnorm_stats: bad arguments (training-mode BatchNorm needs more than one row)");
+  hipLaunchKernelGGL(hct::batch_stats_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, B, D, momentum, mean, var,
+                     running_mean, running_var);
+  HCT_CHECK_LAUNCH("hct_batchnorm_stats");
+  return 0;
+}
+
+int hct_softmax_xent(const float* logits, const int64_t* target, int B, int n_classes, const float* dloss, float* loss,
+                     float* dlogits, void* stream) {
+  HCT_REQUIRE(logits && target && B > 0 && n_classes > 0 && (loss || dlogits), "hct_softmax_xent: bad arguments");
+  hipLaunchKernelGGL(hct::softmax_xent_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, B, n_classes, dloss, loss,
+                     dlogits);
+  HCT_CHECK_LAUNCH("hct_softmax_xent");
+  return 0;
+}
+
+int hct_head_linear_wgrad(const float* x, const float* mean, const float* var, float eps, const float* dlogits, int B, int D,
+                          int n_out, float* dW, float* db, void* stream) {
+  HCT_REQUIRE(x && dlogits && dW && B > 0 && D > 0 && n_out > 0 && (!mean == !var), "hct_head_linear_wgrad: bad arguments");
+  const int64_t n = (int64_t)n_out * D;
+  hipLaunchKernelGGL(hct::head_linear_wgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mean, var,
+                     eps, dlogits, B, D, n_out, dW, db);
+  HCT_CHECK_LAUNCH("hct_head_linear_wgrad");
+  return 0;
+}
 
 int hct_channel_norm(const float* x, const float* mean, const float* var, float eps, void* out, int out_dtype, int64_t rows,
                      int C, void* stream) {

@@ -190,6 +190,24 @@ int hct_query_attention(const float* q, int Q, const void* kv, int kv_dtype, int
 int hct_head_linear(const float* x, int64_t ldx, int nq, const float* mean, const float* var, float eps, const float* W,
                     const float* bias, int act, float* out, int rows, int D, int n_out, void* stream);
 
+/* Linear probing: LinearClassifier in TRAINING mode on frozen (detached) features with nn.CrossEntropyLoss
+ * (main_downstream.py:142-146, :214; engine_downstream.py:70-117).  All fp32, fixed summation orders.
+ *
+ * hct_batchnorm_stats: nn.BatchNorm1d training statistics of x [B, D] (B > 1): mean[k], var[k] = biased variance (what the
+ *   forward normalises with); if running_* are given: running = (1-momentum)*running + momentum*{mean, unbiased variance}.
+ *   The forward itself is hct_head_linear with these mean / var.
+ * hct_softmax_xent: loss = mean_b(logsumexp(logits[b]) - logits[b, target[b]]) (loss may be NULL);
+ *   dlogits[b, c] = (softmax(logits[b])[c] - [c == target[b]]) * (dloss ? *dloss : 1) / B (dlogits may be NULL).
+ * hct_head_linear_wgrad: dW[c, k] = sum_b dlogits[b, c] * (x[b, k] - mean[k]) / sqrt(var[k] + eps), db[c] = sum_b dlogits[b, c]
+ *   (mean = var = NULL: no normalisation; db may be NULL).  The statistics are treated as constants: exact for the
+ *   parameter gradients; the gradient with respect to x (fine-tuning an unfrozen backbone) is not built. */
+int hct_batchnorm_stats(const float* x, int B, int D, float momentum, float* mean, float* var, float* running_mean,
+                        float* running_var, void* stream);
+int hct_softmax_xent(const float* logits, const int64_t* target, int B, int n_classes, const float* dloss, float* loss,
+                     float* dlogits, void* stream);
+int hct_head_linear_wgrad(const float* x, const float* mean, const float* var, float eps, const float* dlogits, int B, int D,
+                          int n_out, float* dW, float* db, void* stream);
+
 /* Device side of the reference's per-sample MAE input transforms, mae3d_transforms(mode='train'), src/data/transforms.py:
  * 193-228: CastToTyped(float32) of the cached volume (fp16 on disk, transforms.py:170-175) -> RandFlipd on spatial axes
  * 0, 1, 2 -> RandShiftIntensityd.  The random draws stay on the host (one byte of flip flags and one offset per sample);

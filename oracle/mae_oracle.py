@@ -446,6 +446,23 @@ def linear_classifier_forward(p: Dict[str, torch.Tensor], x: torch.Tensor) -> to
     return x @ p["linear.weight"].T + p["linear.bias"]
 
 
+def linear_probe_step(p: Dict[str, torch.Tensor], x: torch.Tensor, target: torch.Tensor, momentum: float = 0.1):
+    """One linear-probing step on frozen features (engine_downstream.py:80-102 with TRAIN.LOCK): LinearClassifier in
+    TRAINING mode (classifier.py:21-33: BatchNorm1d batch statistics, biased variance; running statistics updated with the
+    unbiased variance and momentum 0.1), nn.CrossEntropyLoss() (main_downstream.py:214), backward.
+    Returns (logits, loss, {linear.weight, linear.bias gradients}, {running_mean, running_var after the update})."""
+    w = p["linear.weight"].clone().requires_grad_(True)
+    b = p["linear.bias"].clone().requires_grad_(True)
+    mean = x.mean(dim=0)
+    xn = (x - mean) / torch.sqrt(x.var(dim=0, unbiased=False) + 1e-6)
+    logits = xn @ w.T + b
+    loss = (torch.logsumexp(logits, dim=1) - logits[torch.arange(x.shape[0]), target]).mean()
+    loss.backward()
+    stats = {"bn.running_mean": (1 - momentum) * p["bn.running_mean"] + momentum * mean,
+             "bn.running_var": (1 - momentum) * p["bn.running_var"] + momentum * x.var(dim=0, unbiased=True)}
+    return logits.detach(), loss.detach(), {"linear.weight": w.grad, "linear.bias": b.grad}, stats
+
+
 def attention_classifier_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, num_heads: int, num_queries: int,
                                  qk_scale: Optional[float] = None) -> torch.Tensor:
     """AttentionClassifier.forward, classifier.py:73-99 (eval).  x: [B, N, C] token features.  The learnt queries are scaled

@@ -320,6 +320,26 @@ def classifier_fixture():
     assert out.shape == (5, 3) and err < 2e-6, err
     fx["linear"] = dict(ctor=dict(dim=192, num_classes=3), seed0=300, x_seed=31, x_shape=[5, 192], max_abs_dev_oracle=err,
                         state_dict={k: dict(shape=list(v.shape)) for k, v in ref.state_dict().items()}, out=out.flatten().tolist())
+    # the same head in training mode: one linear-probing step (batch statistics, CrossEntropyLoss, backward)
+    ref = LinearClassifier(192, 3).train()
+    ref.load_state_dict(params, strict=True)
+    target = torch.tensor([0, 2, 1, 1, 0])
+    logits = ref(x)
+    loss = torch.nn.CrossEntropyLoss()(logits, target)
+    loss.backward()
+    o_logits, o_loss, o_grads, o_stats = O.linear_probe_step(params, x, target)
+    sd = ref.state_dict()
+    err = max(float((logits.detach() - o_logits).abs().max()), float((loss.detach() - o_loss).abs()),
+              float((ref.linear.weight.grad - o_grads["linear.weight"]).abs().max()),
+              float((ref.linear.bias.grad - o_grads["linear.bias"]).abs().max()),
+              float((sd["bn.running_mean"] - o_stats["bn.running_mean"]).abs().max()),
+              float((sd["bn.running_var"] - o_stats["bn.running_var"]).abs().max()))
+    assert err < 2e-6 and int(sd["bn.num_batches_tracked"]) == 1, err
+    fx["linear_probe_step"] = dict(ctor=dict(dim=192, num_classes=3), seed0=300, x_seed=31, x_shape=[5, 192], target=target.tolist(),
+                                   max_abs_dev_oracle=err, state_dict=fx["linear"]["state_dict"],
+                                   logits=logits.detach().flatten().tolist(), loss=float(loss.detach()),
+                                   grad_weight=ref.linear.weight.grad.flatten().tolist(), grad_bias=ref.linear.bias.grad.tolist(),
+                                   running_mean=sd["bn.running_mean"].tolist(), running_var=sd["bn.running_var"].tolist())
     # AttentionClassifier, one and several learnt queries
     for name, nq, bias, seed0 in (("attention_q1", 1, False, 320), ("attention_q3", 3, True, 340)):
         kw = dict(dim=192, num_classes=4, num_heads=3, qkv_bias=bias, num_queries=nq)

@@ -140,7 +140,7 @@ def _head_inputs(name, e):
         params["cls_token"] = params["cls_token"] * e["cls_token_gain"]
         shp = e["x_shape"]
         x = torch.from_numpy(O.hash_uniform(int(np.prod(shp)), e["x_seed"]).reshape(shp).astype(np.float32)) * e["x_gain"]
-    elif name == "linear":
+    elif name.startswith("linear"):
         shp = e["x_shape"]
         x = torch.from_numpy(O.hash_uniform(int(np.prod(shp)), e["x_seed"]).reshape(shp).astype(np.float32))
     else:
@@ -165,8 +165,10 @@ def test_classifier_heads_oracle_matches_reference_fixture():
     reference's own modules (tests/golden/make_golden.py: classifier_fixture)."""
     import torch
     fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "classifier_heads.json")))
-    assert set(fx) == {"linear", "attention_q1", "attention_q3", "vit_tanh", "vit_linear"}
+    assert set(fx) == {"linear", "linear_probe_step", "attention_q1", "attention_q3", "vit_tanh", "vit_linear"}
     for name, e in fx.items():
+        if name == "linear_probe_step":
+            continue
         params, x = _head_inputs(name, e)
         out = _head_oracle(name, e, params, x)
         want = torch.tensor(e["out"]).reshape(out.shape)
@@ -178,7 +180,7 @@ def test_classifier_modules_mirror_reference_state_dict():
     from headct_foundation_amd import AttentionClassifier, LinearClassifier, ViT
     fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "classifier_heads.json")))
     for name, e in fx.items():
-        cls = LinearClassifier if name == "linear" else AttentionClassifier if name.startswith("attention") else ViT
+        cls = LinearClassifier if name.startswith("linear") else AttentionClassifier if name.startswith("attention") else ViT
         m = cls(**e["ctor"])
         sd = m.state_dict()
         assert list(sd.keys()) == list(e["state_dict"].keys()), name
@@ -186,6 +188,21 @@ def test_classifier_modules_mirror_reference_state_dict():
     import pytest
     import torch
     with pytest.raises(Exception, match="eval"):
-        LinearClassifier(8, 2)(torch.zeros(1, 8))
+        AttentionClassifier(8, 2, num_heads=2)(torch.zeros(1, 3, 8))
+    with pytest.raises(Exception, match="GPU"):
+        LinearClassifier(8, 2)(torch.zeros(2, 8))
     with pytest.raises(Exception, match="GPU"):
         LinearClassifier(8, 2).eval()(torch.zeros(1, 8))
+
+
+def test_linear_probe_step_oracle_matches_reference_fixture():
+    """LinearClassifier.train() + nn.CrossEntropyLoss() + backward of the reference (one step) vs the oracle."""
+    import torch
+    from oracle import mae_oracle as O
+    e = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "classifier_heads.json")))["linear_probe_step"]
+    params, x = _head_inputs("linear_probe_step", e)
+    logits, loss, grads, stats = O.linear_probe_step(params, x, torch.tensor(e["target"]))
+    close = lambda a, b: torch.allclose(a.flatten(), torch.tensor(b).flatten(), rtol=0, atol=2e-6)
+    assert close(logits, e["logits"]) and abs(float(loss) - e["loss"]) < 2e-6
+    assert close(grads["linear.weight"], e["grad_weight"]) and close(grads["linear.bias"], e["grad_bias"])
+    assert close(stats["bn.running_mean"], e["running_mean"]) and close(stats["bn.running_var"], e["running_var"])
