@@ -2,8 +2,8 @@
 
 Mirror of `ViT` (src/models/vit.py:26-173) for the downstream use of a pre-trained encoder: same constructor arguments and
 parameter names (`cls_token`, `register_tokens`, `patch_embedding.*`, `blocks.N.*`, `norm.*`), `forward(x) -> (x,
-hidden_states_out)`: every patch embedded (+ position table), class token, register tokens, the blocks, final LayerNorm
-with eps 1e-6.  Built from the library's primitives (`hct_patch_gather`, `hct_gemm`, `hct_vit_assemble_fwd`,
+hidden_states_out)`: every patch embedded (+ position table, resized trilinearly when the volume is not the constructor's
+size, patch_embedding.py:136-144), class token, register tokens, the blocks, final LayerNorm with eps 1e-6.  Built from the library's primitives (`hct_patch_gather`, `hct_gemm`, `hct_vit_assemble_fwd`,
 `hct_layernorm_fwd`, `hct_attention_fwd`, `hct_head_linear`); there is no autograd and no CPU path.  With
 `classification=True` the class-token head of vit.py:133-137 / :170-171 (Linear, Tanh unless `post_activation` says
 otherwise) is applied and `forward` returns the class scores.  Not built: LoRA, 2-D inputs, the perceptron patch embedding.
@@ -147,24 +147,33 @@ class ViT(nn.Module):
         if not x.is_cuda or not self.cls_token.is_cuda:
             raise _lib.HctError("ViT (HIP) runs on the GPU: move the module and the input to 'cuda' (no CPU fallback exists)")
         B = x.shape[0]
-        if tuple(x.shape[1:]) != (self.in_chans, self.S, self.S, self.S):
-            raise _lib.HctError(f"input shape {tuple(x.shape)} != (B, {self.in_chans}, {self.S}, {self.S}, {self.S})")
+        S = x.shape[-1] if x.dim() == 5 else -1
+        if x.dim() != 5 or tuple(x.shape[1:]) != (self.in_chans, S, S, S) or S <= 0 or S % self.P:
+            raise _lib.HctError(f"input shape {tuple(x.shape)} != (B, {self.in_chans}, S, S, S) with S a multiple of {self.P}")
         self._lib = _lib.load()
         dev = x.device
         with torch.cuda.device(dev):
             self._st = torch.cuda.current_stream().cuda_stream
             dt, tdt = self._dt(), self._tdt()
-            D, L, R, H = self.D, self.L, self.num_register_tokens, self.heads
+            grid = S // self.P
+            D, L, R, H = self.D, grid ** 3, self.num_register_tokens, self.heads
             T = 1 + R + L
             x = x.to(torch.float32).contiguous()
             ids = torch.arange(L, dtype=torch.int32, device=dev).repeat(B, 1).contiguous()
             rows = torch.empty(B * L, self.in_chans * self.P ** 3, dtype=tdt, device=dev)
-            _lib.check(self._lib.hct_patch_gather(x.data_ptr(), ids.data_ptr(), B, self.in_chans, self.S, self.P, L, L, rows.data_ptr(), dt,
+            _lib.check(self._lib.hct_patch_gather(x.data_ptr(), ids.data_ptr(), B, self.in_chans, S, self.P, L, L, rows.data_ptr(), dt,
                                                   self._st), "hct_patch_gather")
             pe = self.patch_embedding
             tok = self._linear(rows, self._weight(pe.patch_embeddings.weight), pe.patch_embeddings.bias, tdt)
             h = torch.empty(B * T, D, dtype=torch.float32, device=dev)
             pos = pe.position_embeddings
+            if pos is not None and grid != self.grid:
+                # a volume of another size: the position table is resized trilinearly for this call, as
+                # PatchEmbeddingBlock.forward does (patch_embedding.py:136-144 -> pos_embed.py:164-217)
+                resized = torch.empty(1, L, D, dtype=torch.float32, device=dev)
+                _lib.check(self._lib.hct_pos_embed_interp3d(pos.data_ptr(), self.grid, resized.data_ptr(), grid, D, 0, self._st),
+                           "hct_pos_embed_interp3d")
+                pos = resized
             _lib.check(self._lib.hct_vit_assemble_fwd(tok.data_ptr(), dt, self.cls_token.data_ptr(),
                                                       self.register_tokens.data_ptr() if R else None,
                                                       pos.data_ptr() if pos is not None else None, B, L, R, D, h.data_ptr(), self._st),

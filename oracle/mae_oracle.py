@@ -418,7 +418,10 @@ def vit_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, patch_size: int, nu
     tok = F.conv3d(x, p["patch_embedding.patch_embeddings.weight"], p["patch_embedding.patch_embeddings.bias"], stride=patch_size)
     tok = tok.flatten(2).transpose(-1, -2)
     if "patch_embedding.position_embeddings" in p:
-        tok = tok + p["patch_embedding.position_embeddings"]
+        pos = p["patch_embedding.position_embeddings"]
+        if pos.shape[1] != tok.shape[1]:  # volume of another size: patch_embedding.py:136-144 -> pos_embed.py:164-217
+            pos = interpolate_pos_embed_3d(pos, round(tok.shape[1] ** (1.0 / 3.0)), 0)
+        tok = tok + pos
     h = torch.cat((p["cls_token"].expand(B, -1, -1), tok), dim=1)
     if "register_tokens" in p:
         h = torch.cat((h[:, :1], p["register_tokens"].expand(B, -1, -1), h[:, 1:]), dim=1)

@@ -300,6 +300,14 @@ def vit_fixture():
     fx = dict(ctor=dict(kw, img_size=32, patch_size=16), max_abs_dev_oracle=err,
               state_dict={k: dict(shape=list(v.shape)) for k, v in ref.state_dict().items()},  # the reference's key order
               out=sample(out, 512), hidden=[sample(h, 256) for h in hidden])
+    # the same model on a 48^3 volume: PatchEmbeddingBlock.forward resizes the position table (2^3 -> 3^3) for the call
+    x48 = torch.from_numpy(O.hash_uniform(2 * 48 ** 3, 9).reshape(2, 1, 48, 48, 48).astype(np.float32)) * 0.5 + 0.5
+    with torch.no_grad():
+        out48, hidden48 = ref(x48)
+    o_out48, o_hidden48 = O.vit_forward(params, x48, 16, 3, 2)
+    err48 = max(float((out48 - o_out48).abs().max()), *(float((a - b).abs().max()) for a, b in zip(hidden48, o_hidden48)))
+    assert out48.shape == (2, 1 + 2 + 27, 192) and err48 < 5e-6, err48
+    fx["resized_48"] = dict(x_seed=9, max_abs_dev_oracle=err48, out=sample(out48, 512), hidden=[sample(h, 256) for h in hidden48])
     with open(os.path.join(HERE, "vit_features.json"), "w") as f:
         json.dump(fx, f)
 

@@ -147,6 +147,20 @@ def test_vit_feature_extraction_vs_oracle_and_reference_fixture(lib, cuda, dtype
         for t, entry in [(out, fx["out"])] + list(zip(hidden, fx["hidden"])):
             got, want, l2, l2w = sample_of(t, entry)
             assert torch.allclose(got, want, rtol=1e-3, atol=1e-4)
+    # a volume of another size (48^3 on a 32^3 model): position table resized on the device for the call
+    r = fx["resized_48"]
+    x48 = torch.from_numpy(O.hash_uniform(2 * 48 ** 3, r["x_seed"]).reshape(2, 1, 48, 48, 48).astype(np.float32)) * 0.5 + 0.5
+    out, hidden = model(x48.to(cuda))
+    o_out, o_hidden = O.vit_forward(params, x48, 16, 3, 2)
+    assert out.shape == (2, 30, 192) and rel_err(out, o_out) < tol
+    for a, b in zip(hidden, o_hidden):
+        assert rel_err(a, b) < tol
+    if dtype == "fp32":
+        for t, entry in [(out, r["out"])] + list(zip(hidden, r["hidden"])):
+            got, want, l2, l2w = sample_of(t, entry)
+            assert torch.allclose(got, want, rtol=1e-3, atol=1e-4)
+    with pytest.raises(Exception, match="multiple of 16"):
+        model(torch.zeros(1, 1, 40, 40, 40, device=cuda))
 
 
 @pytest.mark.parametrize("name", ["linear", "attention_q1", "attention_q3", "vit_tanh", "vit_linear"])

@@ -128,6 +128,14 @@ def test_vit_feature_extraction_against_reference_fixture():
     for t, entry in [(out, fx["out"])] + list(zip(hidden, fx["hidden"])):
         got, want, l2, l2w = sample_of(t, entry)
         assert torch.allclose(got, want, rtol=0, atol=5e-6) and abs(l2 - l2w) < 1e-4 * l2w
+    # same weights on a 48^3 volume: the position table is resized for the call (patch_embedding.py:136-144)
+    r = fx["resized_48"]
+    x48 = torch.from_numpy(O.hash_uniform(2 * 48 ** 3, r["x_seed"]).reshape(2, 1, 48, 48, 48).astype(np.float32)) * 0.5 + 0.5
+    out, hidden = O.vit_forward(params, x48, 16, 3, 2)
+    assert list(out.shape) == r["out"]["shape"] == [2, 30, 192]
+    for t, entry in [(out, r["out"])] + list(zip(hidden, r["hidden"])):
+        got, want, l2, l2w = sample_of(t, entry)
+        assert torch.allclose(got, want, rtol=0, atol=5e-6) and abs(l2 - l2w) < 1e-4 * l2w
 
 
 def _head_inputs(name, e):
