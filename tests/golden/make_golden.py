@@ -2,8 +2,8 @@
 
 Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
-Imports the reference's own src/models/mae.py, attentionblock.py, patch_embedding.py,
-pos_embed.py, misc.py, lr_sched.py and engine_pretrain_mae.py from /root/reference,
+Imports the reference's own src/models/mae.py, vit.py, classifier.py, attentionblock.py,
+patch_embedding.py, pos_embed.py, misc.py, lr_sched.py and engine_pretrain_mae.py from /root/reference,
 with stand-ins registered in sys.modules for the seven third-party symbols that are
 absent from this image (timm to_2tuple/to_3tuple; MONAI Conv,
 trunc_normal_, MLPBlock, ensure_tuple_rep, optional_import, look_up_option).
