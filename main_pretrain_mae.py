@@ -11,6 +11,8 @@ import os
 import random
 import warnings
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL between ranks (before HIP initialises)
+
 import numpy as np
 import torch
 import torch.distributed as dist
