@@ -250,3 +250,25 @@ def test_linear_probe_step_vs_oracle_and_reference_fixture(lib, cuda):
         model(xg.clone().requires_grad_(True))
     bad = cross_entropy(model(xg), torch.tensor([0, 7, 1, 1, 0], device=cuda))
     assert not torch.isfinite(bad.detach())
+
+
+@pytest.mark.parametrize("name,dtype,tol_loss,tol_grad", [("micro", "fp32", 1e-3, 1e-3), ("tiny", "bf16", 5e-3, 6e-2)])
+def test_odd_and_changing_batch_sizes_vs_oracle(lib, cuda, name, dtype, tol_loss, tol_grad):
+    """Ragged row counts (batch 3, 1, 5 -> token rows that are no multiple of any tile) on ONE model instance, as the
+    short last batch of an epoch produces them: each batch size gets its own plan; loss and gradients vs the oracle."""
+    cfg = O.CONFIGS[name]
+    params = O.make_params(cfg, 0)
+    model = build_hip_model(cfg, params, cuda, dtype)
+    model.train()
+    for batch in (3, 1, 5, 3):
+        x, noise = O.make_volume(cfg, batch, 20 + batch), O.make_noise(cfg, batch, 20 + batch)
+        o_loss, o_pred, o_mask, o_grads, _ = O.forward_backward(cfg, params, x, noise)
+        model.zero_grad()
+        loss, _, _ = model(x.to(cuda), noise=noise.to(cuda))
+        loss.backward()
+        torch.cuda.synchronize()
+        assert abs(float(loss.detach()) - float(o_loss)) / abs(float(o_loss)) < tol_loss, batch
+        assert torch.equal(model.last_mask(batch).cpu(), o_mask)
+        grads = grads_by_name(model)
+        worst = max((rel_err(grads[k], o_grads[k]), k) for k in grads if not k.endswith("qkv.bias"))
+        assert worst[0] < tol_grad, (batch, worst)
