@@ -272,3 +272,22 @@ def test_odd_and_changing_batch_sizes_vs_oracle(lib, cuda, name, dtype, tol_loss
         grads = grads_by_name(model)
         worst = max((rel_err(grads[k], o_grads[k]), k) for k in grads if not k.endswith("qkv.bias"))
         assert worst[0] < tol_grad, (batch, worst)
+
+
+@pytest.mark.parametrize("mask_ratio", [0.5, 0.9])
+def test_other_mask_ratios_vs_oracle(lib, cuda, mask_ratio):
+    """The number of kept tokens follows int(L * (1 - mask_ratio)) (mae.py:204): other ratios than the fixtures' against the
+    oracle, fp32, rel 1e-3."""
+    import dataclasses
+    cfg = dataclasses.replace(O.CONFIGS["micro"], mask_ratio=mask_ratio)
+    params = O.make_params(cfg, 3)
+    x, noise = O.make_volume(cfg, 2, 3), O.make_noise(cfg, 2, 3)
+    o_loss, o_pred, o_mask, o_grads, _ = O.forward_backward(cfg, params, x, noise)
+    model, loss = _run_hip(cfg, params, x, noise, cuda, "fp32")
+    assert int(o_mask.sum()) == 2 * (cfg.num_patches - int(cfg.num_patches * (1 - mask_ratio)))
+    assert abs(loss - float(o_loss)) / abs(float(o_loss)) < 1e-3
+    assert torch.equal(model.last_mask(2).cpu(), o_mask)
+    assert rel_err(model.last_pred(2), o_pred) < 1e-3
+    grads = grads_by_name(model)
+    worst = max((rel_err(grads[k], o_grads[k]), k) for k in grads if not k.endswith("qkv.bias"))
+    assert worst[0] < 1e-3, worst
