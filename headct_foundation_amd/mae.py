@@ -30,24 +30,28 @@ def _to_3tuple(x):
 
 
 def build_sincos_position_embedding(grid_size, embed_dim: int, spatial_dims: int = 3, temperature: float = 10000.0):
-    """3-D sin-cos table [1, L, D] (src/utils/pos_embed.py:51-78)."""
+    """Fixed 3-D sine/cosine position table [1, L, D] (contract: src/utils/pos_embed.py:51-78).
+
+    D/6 frequencies 1 / T^(j / (D/6)); token (a, b, c) of the row-major grid gets, in this order, sin and cos of its b, a
+    and c coordinate times the frequencies.  (The reference names the axes so that the second grid axis comes first; for
+    the cubic grids of this path only that order matters.)  fp32 throughout, one multiply per entry, so the table is
+    bit-identical to the reference's (tests/golden/sincos.json)."""
     if spatial_dims != 3:
         raise NotImplementedError(f"Spatial Dimension Size {spatial_dims} Not Implemented!")
-    h, w, d = _to_3tuple(grid_size)
-    # the reference builds grid_h from w and grid_w from h (pos_embed.py:54-55)
-    grid_h = torch.arange(w, dtype=torch.float32)
-    grid_w = torch.arange(h, dtype=torch.float32)
-    grid_d = torch.arange(d, dtype=torch.float32)
-    grid_h, grid_w, grid_d = torch.meshgrid(grid_h, grid_w, grid_d, indexing="ij")
-    assert embed_dim % 6 == 0, "Embed dimension must be divisible by 6 for 3D sin-cos position embedding"
-    pos_dim = embed_dim // 6
-    omega = torch.arange(pos_dim, dtype=torch.float32) / pos_dim
-    omega = 1.0 / (temperature ** omega)
-    out_h = torch.einsum("m,d->md", [grid_h.flatten(), omega])
-    out_w = torch.einsum("m,d->md", [grid_w.flatten(), omega])
-    out_d = torch.einsum("m,d->md", [grid_d.flatten(), omega])
-    return torch.cat([torch.sin(out_w), torch.cos(out_w), torch.sin(out_h), torch.cos(out_h),
-                      torch.sin(out_d), torch.cos(out_d)], dim=1)[None, :, :]
+    if embed_dim % 6:
+        raise AssertionError("Embed dimension must be divisible by 6 for 3D sin-cos position embedding")
+    n0, n1, n2 = _to_3tuple(grid_size)
+    nfreq = embed_dim // 6
+    freq = 1.0 / (temperature ** (torch.arange(nfreq, dtype=torch.float32) / nfreq))
+    # coordinates of every token along the three axes of the (n1, n0, n2) meshgrid the reference builds
+    axes = [torch.arange(n, dtype=torch.float32) for n in (n1, n0, n2)]
+    shape = (n1, n0, n2)
+    coords = [ax.reshape([-1 if k == i else 1 for k in range(3)]).expand(shape).reshape(-1) for i, ax in enumerate(axes)]
+    parts = []
+    for i in (1, 0, 2):
+        angle = coords[i][:, None] * freq[None, :]
+        parts += [torch.sin(angle), torch.cos(angle)]
+    return torch.cat(parts, dim=1).unsqueeze(0)
 
 
 class _Holder(nn.Module):

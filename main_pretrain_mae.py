@@ -9,7 +9,6 @@ import argparse
 import json
 import os
 import random
-import warnings
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL between ranks (before HIP initialises)
 
@@ -63,104 +62,117 @@ def parse_option():
     return args, config
 
 
+def build_model(config, device):
+    """MaskedAutoencoderViT from the MAE.* block of the config (every constructor argument of mae.py:22-42 has a key)."""
+    mae = config.MAE
+    if mae.NORM_LAYER != 'layernorm':
+        raise ValueError("MAE.NORM_LAYER must be 'layernorm' on the HIP path (RMSNorm is outside the hot path)")
+    kwargs = {key.lower(): getattr(mae, key) for key in (
+        "INPUT_SIZE", "PATCH_SIZE", "MASK_RATIO", "IN_CHANS", "DROPOUT_RATE", "SPATIAL_DIMS", "PATCH_EMBED", "POS_EMBED",
+        "ENCODER_DEPTH", "ENCODER_EMBED_DIM", "ENCODER_MLP_DIM", "ENCODER_NUM_HEADS", "DECODER_DEPTH", "DECODER_EMBED_DIM",
+        "DECODER_MLP_DIM", "DECODER_NUM_HEADS", "NORM_PIX_LOSS", "USE_BIAS")}
+    return MaskedAutoencoderViT(norm_layer=nn.LayerNorm, compute_dtype=mae.COMPUTE_DTYPE, **kwargs).to(device)
+
+
+def load_pretrained(config, model, logger):
+    """MODEL.PRETRAINED -> the checkpoint dict (or None).  Weights go into `model` non-strictly after the `module.` prefix
+    is dropped; a learnable position table saved at another resolution is resized first (main_pretrain_mae.py:125-134)."""
+    path = config.MODEL.PRETRAINED
+    if not path:
+        return None
+    # the file holds tensors and python scalars only, so the restricted unpickler is enough
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    weights = {name.replace("module.", ""): t for name, t in ckpt['state_dict'].items()}
+    interpolate_pos_embed(model, weights)
+    have = model.state_dict()["decoder_pos_embed"].shape
+    want = weights.get("decoder_pos_embed")
+    if want is not None and want.shape != have:
+        # only the encoder table is resized (as in the reference, whose load_state_dict then raises on this tensor)
+        raise SystemExit(f"size mismatch for decoder_pos_embed: checkpoint {tuple(want.shape)} vs model {tuple(have)}")
+    report = model.load_state_dict(weights, strict=False)
+    logger.info(f"Load Pretrained Model: {report} for Architecture: {config.MODEL.NAME}")
+    return ckpt
+
+
+def scale_learning_rate(config, world_size, steps_per_epoch, logger):
+    """Linear LR scaling rule of the recipe (main_pretrain_mae.py:141-154): BASE_LR *= global batch / 256, MIN_LR =
+    BASE_LR / 1000; returns (warm-up steps, total steps)."""
+    global_batch = config.DATA.BATCH_SIZE * world_size
+    total = steps_per_epoch * config.TRAIN.MAX_EPOCHS
+    warmup = int(config.TRAIN.PER_WARMUP * total)
+    config.defrost()
+    config.TRAIN.BASE_LR = config.TRAIN.BASE_LR * global_batch / 256
+    config.TRAIN.MIN_LR = config.TRAIN.BASE_LR * 1e-3
+    config.freeze()
+    logger.info(f"Effective Learning Rate: {config.TRAIN.BASE_LR}, Effective Batch Size: {global_batch}, Max Epochs: {config.TRAIN.MAX_EPOCHS}")
+    logger.info(f"Number of Warmup Steps: {warmup}, Total Steps: {total}")
+    return warmup, total
+
+
 def main(config, wandb_run, logger):
-    max_epochs = config.TRAIN.MAX_EPOCHS
-    val_every = config.TRAIN.VAL_EVERY
     if config.MODEL.NAME != "mae":
         raise ValueError(f"Model {config.MODEL.NAME} not supported")
     if not torch.cuda.is_available():
         raise SystemExit("main_pretrain_mae.py (HIP) needs an MI355X: the MAE hot path has no CPU fallback")
+    rank, world = dist.get_rank(), dist.get_world_size()
     device = torch.device("cuda", torch.cuda.current_device())
-    train_loader, val_loader, test_loader = get_pretrain_dataloaders(config, device, dist.get_rank(), dist.get_world_size())
+    train_loader, val_loader, test_loader = get_pretrain_dataloaders(config, device, rank, world)
 
-    if config.MAE.NORM_LAYER != 'layernorm':
-        raise ValueError("MAE.NORM_LAYER must be 'layernorm' on the HIP path (RMSNorm is outside the hot path)")
-    model = MaskedAutoencoderViT(
-        input_size=config.MAE.INPUT_SIZE, patch_size=config.MAE.PATCH_SIZE, mask_ratio=config.MAE.MASK_RATIO,
-        in_chans=config.MAE.IN_CHANS, dropout_rate=config.MAE.DROPOUT_RATE, spatial_dims=config.MAE.SPATIAL_DIMS,
-        patch_embed=config.MAE.PATCH_EMBED, pos_embed=config.MAE.POS_EMBED, encoder_depth=config.MAE.ENCODER_DEPTH,
-        encoder_embed_dim=config.MAE.ENCODER_EMBED_DIM, encoder_mlp_dim=config.MAE.ENCODER_MLP_DIM,
-        encoder_num_heads=config.MAE.ENCODER_NUM_HEADS, decoder_depth=config.MAE.DECODER_DEPTH,
-        decoder_embed_dim=config.MAE.DECODER_EMBED_DIM, decoder_mlp_dim=config.MAE.DECODER_MLP_DIM,
-        decoder_num_heads=config.MAE.DECODER_NUM_HEADS, norm_pix_loss=config.MAE.NORM_PIX_LOSS, use_bias=config.MAE.USE_BIAS,
-        norm_layer=nn.LayerNorm, compute_dtype=config.MAE.COMPUTE_DTYPE,
-    ).to(device)
+    bare = build_model(config, device)
+    ckpt = load_pretrained(config, bare, logger)
+    # one replica per GPU; gradients are averaged over RCCL in buckets while the backward is still running
+    model = DistributedDataParallel(bare, device_ids=[device], broadcast_buffers=False, find_unused_parameters=True)
 
-    loaded_state_dict = None
-    if config.MODEL.PRETRAINED:
-        # tensors only (weights_only=True): reference checkpoints hold plain tensors / python scalars
-        loaded_state_dict = torch.load(config.MODEL.PRETRAINED, map_location=torch.device('cpu'), weights_only=True)
-        new_sd = {k.replace("module.", ""): v for k, v in loaded_state_dict['state_dict'].items()}
-        # resuming at another resolution: resize the learnable position table (main_pretrain_mae.py:132)
-        interpolate_pos_embed(model, new_sd)
-        own = model.state_dict()
-        if "decoder_pos_embed" in new_sd and new_sd["decoder_pos_embed"].shape != own["decoder_pos_embed"].shape:
-            # the reference stops here as well: interpolate_pos_embed only treats the encoder table, and load_state_dict
-            # raises on a size mismatch even with strict=False
-            raise SystemExit(f"size mismatch for decoder_pos_embed: checkpoint {tuple(new_sd['decoder_pos_embed'].shape)} vs "
-                             f"model {tuple(own['decoder_pos_embed'].shape)}")
-        msg = model.load_state_dict(new_sd, strict=False)
-        logger.info(f"Load Pretrained Model: {msg} for Architecture: {config.MODEL.NAME}")
-
-    model = DistributedDataParallel(model, device_ids=[device], broadcast_buffers=False, find_unused_parameters=True)
-
-    world_size = dist.get_world_size()
-    effective_batch_size = config.DATA.BATCH_SIZE * world_size
-    total_steps = len(train_loader) * config.TRAIN.MAX_EPOCHS
-    num_warmup_steps = int(config.TRAIN.PER_WARMUP * total_steps)
-    config.defrost()
-    config.TRAIN.BASE_LR = config.TRAIN.BASE_LR * effective_batch_size / 256  # main_pretrain_mae.py:149-151
-    config.TRAIN.MIN_LR = config.TRAIN.BASE_LR * 1e-3
-    config.freeze()
-    logger.info(f"Effective Learning Rate: {config.TRAIN.BASE_LR}, Effective Batch Size: {effective_batch_size}, Max Epochs: {config.TRAIN.MAX_EPOCHS}")
-    logger.info(f"Number of Warmup Steps: {num_warmup_steps}, Total Steps: {total_steps}")
-
+    warmup, total = scale_learning_rate(config, world, len(train_loader), logger)
     optimizer = get_optimizer(config, config.TRAIN.BASE_LR, [model])
-    scheduler = get_lr_scheduler(config, optimizer, num_warmup_steps, total_steps, config.TRAIN.MIN_LR)
-    start_epoch = 0
-    if loaded_state_dict is not None:
-        optimizer, scheduler, start_epoch = load_optimizer(optimizer, scheduler, loaded_state_dict, logger)
+    scheduler = get_lr_scheduler(config, optimizer, warmup, total, config.TRAIN.MIN_LR)
+    first_epoch = 0
+    if ckpt is not None:
+        optimizer, scheduler, first_epoch = load_optimizer(optimizer, scheduler, ckpt, logger)
 
-    train_loss = trainer(config=config, model=model, train_loader=train_loader, val_loader=val_loader, optimizer=optimizer,
-                         scheduler=scheduler, start_epoch=start_epoch, max_epochs=max_epochs, val_every=val_every, logger=logger,
-                         device=device, wandb_run=wandb_run)
-    logger.info(f"Train completed, best train reconstruction loss: {train_loss:.4f}")
-    test_loss = tester(config=config, model=model, test_loader=test_loader, logger=logger, device=device, wandb_run=wandb_run)
-    logger.info(f"Test completed, best test reconstruction loss: {test_loss:.4f}")
+    best = trainer(config=config, model=model, train_loader=train_loader, val_loader=val_loader, optimizer=optimizer,
+                   scheduler=scheduler, start_epoch=first_epoch, max_epochs=config.TRAIN.MAX_EPOCHS,
+                   val_every=config.TRAIN.VAL_EVERY, logger=logger, device=device, wandb_run=wandb_run)
+    logger.info(f"Train completed, best train reconstruction loss: {best:.4f}")
+    held_out = tester(config=config, model=model, test_loader=test_loader, logger=logger, device=device, wandb_run=wandb_run)
+    logger.info(f"Test completed, best test reconstruction loss: {held_out:.4f}")
     cleanup()
 
 
 def init_seed(seed):
+    """Seed every generator the run draws from (torch CPU + all GPUs, numpy, random)."""
+    random.seed(seed)
+    np.random.seed(seed)
     torch.manual_seed(seed)
     if torch.cuda.is_available():
-        torch.cuda.manual_seed(seed)
         torch.cuda.manual_seed_all(seed)
-    np.random.seed(seed)
-    random.seed(seed)
+
+
+def start_wandb(config, logger):
+    if not config.WANDB.WANDB_ENABLE or dist.get_rank() != 0:
+        return None
+    try:
+        import wandb
+    except ImportError:
+        logger.info("wandb is not installed; continuing without it")
+        return None
+    summary = {"learning_rate": config.TRAIN.BASE_LR, "batch_size": config.DATA.BATCH_SIZE, "epochs": config.TRAIN.MAX_EPOCHS,
+               "backbone": config.MODEL.NAME}
+    return wandb.init(name=config.LOG.FILENAME, project=config.WANDB.PROJECT, config=summary)
 
 
 if __name__ == "__main__":
-    warnings.filterwarnings("ignore", message="You are using `torch.load` with `weights_only=False`")
     args, config = parse_option()
     init_distributed_mode(args)
-    seed = config.SEED + dist.get_rank()  # each rank draws different masks (main_pretrain_mae.py:213)
-    init_seed(seed)
-    logger = create_logger(output_dir=config.LOG.OUTPUT_DIR, dist_rank=dist.get_rank(), name=config.LOG.FILENAME)
-    if dist.get_rank() == 0 and config.OUTPUT:
+    rank = dist.get_rank()
+    init_seed(config.SEED + rank)  # a different mask / augmentation stream per rank (main_pretrain_mae.py:213)
+    logger = create_logger(output_dir=config.LOG.OUTPUT_DIR, dist_rank=rank, name=config.LOG.FILENAME)
+    if rank == 0 and config.OUTPUT:
         os.makedirs(config.OUTPUT, exist_ok=True)
-        path = os.path.join(config.OUTPUT, f"{config.LOG.FILENAME}.json")
-        with open(path, "w") as f:
+        dump_path = os.path.join(config.OUTPUT, f"{config.LOG.FILENAME}.json")
+        with open(dump_path, "w") as f:
             f.write(config.dump())
-        logger.info(f"Full config saved to {path}")
+        logger.info(f"Full config saved to {dump_path}")
     logger.info(config.dump())
     logger.info(json.dumps(vars(args)))
-    wandb_run = None
-    if config.WANDB.WANDB_ENABLE and dist.get_rank() == 0:
-        try:
-            import wandb
-            wandb_run = wandb.init(name=config.LOG.FILENAME, project=config.WANDB.PROJECT,
-                                   config={"learning_rate": config.TRAIN.BASE_LR, "batch_size": config.DATA.BATCH_SIZE,
-                                           "epochs": config.TRAIN.MAX_EPOCHS, "backbone": config.MODEL.NAME})
-        except ImportError:
-            logger.info("wandb is not installed; continuing without it")
-    main(config, wandb_run, logger)
+    main(config, start_wandb(config, logger), logger)
