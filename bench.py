@@ -38,6 +38,16 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MIC
 VITB = dict(input_size=96, patch_size=16, mask_ratio=0.75, in_chans=1, dropout_rate=0.0, spatial_dims=3, patch_embed="conv",
             pos_embed="sincos", encoder_depth=12, encoder_embed_dim=768, encoder_mlp_dim=3072, encoder_num_heads=12,
             decoder_depth=8, decoder_embed_dim=768, decoder_mlp_dim=3072, decoder_num_heads=16, norm_pix_loss=False, use_bias=False)
+# BASELINE config #4 (`--config vitl`): ViT-L/16^3 encoder on 128^3 volumes, learnable position table (the reference's default
+# POS_EMBED), decoder 768 x 8 layers x 16 heads; 513-token decoder sequences = the attention-tile LDS stress case
+VITL = dict(VITB, input_size=128, pos_embed="learnable", encoder_depth=24, encoder_embed_dim=1024, encoder_mlp_dim=4096,
+            encoder_num_heads=16)
+WORKLOADS = {
+    "vitb": (VITB, 256, "BASELINE config #2: MAE ViT-B/16^3, 96^3x1ch, mask 0.75, full train step (fwd+bwd+clip+AdamW+LR)",
+             "CT-volumes/sec MAE pretrain step (96^3, ViT-B/16^3, mask 0.75)"),
+    "vitl": (VITL, 64, "BASELINE config #4: MAE ViT-L/16^3, 128^3x1ch, mask 0.75, decoder 768x8x16, full train step",
+             "CT-volumes/sec MAE pretrain step (128^3, ViT-L/16^3, mask 0.75)"),
+}
 
 
 def algorithmic_train_flops_per_volume(c) -> float:
@@ -107,7 +117,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="volumes per GPU")
+    ap.add_argument("--config", default="vitb", choices=sorted(WORKLOADS), help="vitb = BASELINE config #2 (the headline metric), vitl = config #4")
+    ap.add_argument("--batch", type=int, default=0, help="volumes per GPU (default: 256 for vitb, 64 for vitl)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket the dominant kernel with HIP events")
@@ -144,24 +155,24 @@ def main():
             dist.init_process_group("nccl", device_id=device)
 
     lib = _lib.load()
-    B, G = args.batch, world
+    arch, default_batch, workload, metric = WORKLOADS[args.config]
+    B, G = args.batch or default_batch, world
+    S = arch["input_size"]
     torch.manual_seed(42)  # reference init scheme at seed 42 (same weights on every rank; DDP broadcasts rank 0's anyway)
-    model = MaskedAutoencoderViT(**VITB, compute_dtype=args.dtype).to(device)
+    model = MaskedAutoencoderViT(**arch, compute_dtype=args.dtype).to(device)
     ddp = DistributedDataParallel(model, device_ids=[device], bucket_cap_mb=args.bucket_mb) if world > 1 else model
     total_steps = max(1000, args.steps + args.warmup)
     base_lr = 1.5e-4 * B * G / 256  # main_pretrain_mae.py:149-151
     opt = HipAdamW(ddp, lr=base_lr, weight_decay=5e-3, betas=(0.9, 0.95))
     sched = get_cosine_schedule_with_warmup(opt, int(0.05 * total_steps), total_steps, lr_end=base_lr * 1e-3)
 
-    gen = torch.Generator(device=device)
-    gen.manual_seed(42 + rank)  # main_pretrain_mae.py:213
-    pool = [torch.rand(B, 1, 96, 96, 96, device=device, generator=gen) for _ in range(4)]
-    noises = [torch.rand(B, model.num_patches, device=device, generator=gen) for _ in range(4)]
+    torch.manual_seed(42 + rank)  # main_pretrain_mae.py:213: every rank draws its own volumes and masks
+    pool = [torch.rand(B, 1, S, S, S, device=device) for _ in range(4)]
     losses = torch.zeros(args.steps + args.warmup, device=device)
 
     def step(i):
         opt.zero_grad()
-        loss, _, _ = ddp(pool[i % 4], noise=noises[i % 4])
+        loss, _, _ = ddp(pool[i % 4])  # the masking noise is drawn inside forward, as in the reference (mae.py:206)
         loss.backward()
         clip_gradients(ddp, 3.0)
         opt.step()
@@ -202,13 +213,15 @@ def main():
     roof = None
     traf = pmc_traffic()
     if prof:
-        ms, n, w = C.c_double(), C.c_int64(), C.c_double()
+        ms, n, w, nt_bytes = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
         _lib.check(lib.hct_prof_read(0, C.byref(ms), C.byref(n), C.byref(w)), "hct_prof_read")
+        _lib.check(lib.hct_prof_read_bytes(0, C.byref(nt_bytes)), "hct_prof_read_bytes")
         if n.value and ms.value > 0:
             ach = w.value / (ms.value * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "gemm_bf16_nt256_kernel<*> (all epilogue modes)", "achieved": round(ach, 2),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": (traf or {}).get("hbm_bytes_per_launch"), "traffic_detail": traf,
                     "algorithmic_TFLOP_per_launch": round(w.value / n.value / 1e12, 4),
+                    "algorithmic_bytes_per_launch": round(nt_bytes.value / n.value),
                     "launches_per_step": n.value // max(1, (args.steps + 3) // 4), "sampled_steps": (args.steps + 3) // 4, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                     "time_share_of_step": round(ms.value * 1e-3 * args.steps / ((args.steps + 3) // 4) / elapsed, 4)}
         extra = {}
@@ -219,13 +232,13 @@ def main():
         lib.hct_prof_reset()
     if rank == 0:
         vols = B * G * args.steps
-        flops_vol = algorithmic_train_flops_per_volume(VITB)
+        flops_vol = algorithmic_train_flops_per_volume(arch)
         out = {
-            "metric": "CT-volumes/sec MAE pretrain step (96^3, ViT-B/16^3, mask 0.75)",
+            "metric": metric,
             "value": round(vols / elapsed, 2), "unit": "CT-volumes/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE config #2: MAE ViT-B/16^3, 96^3x1ch, mask 0.75, full train step (fwd+bwd+clip+AdamW+LR)",
+            "config": {"workload": workload,
                        "per_gpu_batch": B, "global_batch": B * G, "parallelism": f"dp{G}", "init": "reference init, seed 42",
                        "algorithmic_GFLOP_per_volume": round(flops_vol / 1e9, 2)},
             "step_mfma_frac": round(vols / elapsed * flops_vol / G / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -233,7 +246,7 @@ def main():
         }
         if prof and extra:
             out["other_kernels"] = extra
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "vitb":  # the CPU sample is the headline workload
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

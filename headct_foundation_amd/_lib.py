@@ -34,7 +34,7 @@ class GemmArgs(C.Structure):
 
 class MaeConfig(C.Structure):
     _fields_ = [
-        ("input_size", c_int), ("patch_size", c_int), ("in_chans", c_int), ("mask_ratio", c_float),
+        ("input_size", c_int), ("patch_size", c_int), ("in_chans", c_int), ("mask_ratio", C.c_double),
         ("pos_embed", c_int),
         ("encoder_depth", c_int), ("encoder_embed_dim", c_int), ("encoder_mlp_dim", c_int), ("encoder_num_heads", c_int),
         ("decoder_depth", c_int), ("decoder_embed_dim", c_int), ("decoder_mlp_dim", c_int), ("decoder_num_heads", c_int),
@@ -58,7 +58,7 @@ _PROTOS = {
     "hct_set_cu_reserve": (None, [c_int]),
     "hct_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p, c_size_t, c_void_p]),
     "hct_mask_rank": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "hct_patch_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "hct_patch_gather": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "hct_encoder_assemble_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "hct_encoder_assemble_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "hct_assemble_bwd_workspace_bytes": (c_size_t, [c_int]),
@@ -72,7 +72,7 @@ _PROTOS = {
     "hct_decoder_assemble_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "hct_decoder_assemble_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                          c_void_p, c_size_t, c_void_p]),
-    "hct_masked_mse": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hct_masked_mse": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hct_unpatchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "hct_vit_assemble_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "hct_channel_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int64, c_int, c_void_p]),
@@ -97,6 +97,7 @@ _PROTOS = {
     "hct_prof_enable": (None, [c_int]),
     "hct_prof_reset": (None, []),
     "hct_prof_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double)]),
+    "hct_prof_read_bytes": (c_int, [c_int, C.POINTER(C.c_double)]),
     "hct_mae_plan_create": (c_void_p, [C.POINTER(MaeConfig), c_int, c_int]),
     "hct_mae_plan_destroy": (None, [c_void_p]),
     "hct_mae_plan_num_params": (c_int, [c_void_p]),
@@ -104,13 +105,14 @@ _PROTOS = {
     "hct_mae_plan_param_elems": (c_int64, [c_void_p]),
     "hct_mae_plan_bf16_t_elems": (c_int64, [c_void_p]),
     "hct_mae_plan_workspace_bytes": (c_size_t, [c_void_p]),
+    "hct_mae_plan_len_keep": (c_int, [c_void_p]),
     "hct_mae_plan_bind": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "hct_mae_refresh_weights": (c_int, [c_void_p, c_int, c_void_p]),
-    "hct_mae_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hct_mae_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p]),
     "hct_mae_set_loss_grad": (c_int, [c_void_p, c_void_p]),
     "hct_mae_num_backward_stages": (c_int, [c_void_p]),
     "hct_mae_backward_stage_range": (c_int, [c_void_p, c_int, C.POINTER(c_int64), C.POINTER(c_int64)]),
-    "hct_mae_backward_stage": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "hct_mae_backward_stage": (c_int, [c_void_p, c_int, c_void_p]),
     "hct_mae_plan_activation": (c_void_p, [c_void_p, C.c_char_p, C.POINTER(c_int64), C.POINTER(c_int64), C.POINTER(c_int)]),
 }
 

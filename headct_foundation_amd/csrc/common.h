@@ -10,6 +10,8 @@
 namespace hct {
 
 typedef __bf16 bf16;
+typedef _Float16 f16;  // IEEE half: storage type of cached input volumes only (transforms.py:171-178 cast)
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -35,6 +37,12 @@ int check_hip(hipError_t e, const char* what);
     }                                \
   } while (0)
 
+// masked MSE with a host-side gradient scale folded into dpred (training forward of the plan; elementwise.hip)
+int masked_mse_launch(const void* pred, int pred_dtype, const void* x, int x_dtype, const float* mask, int B, int C, int S, int P,
+                      int norm_pix, float mask_sum, float* row_loss, float* loss, void* dpred, const float* dpred_scale,
+                      float host_scale, hipStream_t s);
+// buf[i] *= *scale unless *scale == 1 (every block then leaves after one scalar load)
+int scale_unless_one(void* buf, int dtype, int64_t n, const float* scale, hipStream_t s);
 // out[d] = sum_{b < nblk} partial[b*D + d]  (fixed order; elementwise.hip)
 int fold_rows(const float* partial, int nblk, int D, float* out, hipStream_t s);
 
@@ -64,6 +72,18 @@ template <> struct Vec4<bf16> {
     *reinterpret_cast<bf16x4*>(p) = o;
   }
 };
+
+template <> struct Vec4<f16> {
+  static __device__ __forceinline__ f32x4 load(const f16* p) {
+    f16x4 v = *reinterpret_cast<const f16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
+  static __device__ __forceinline__ void store(f16* p, f32x4 v) {
+    f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    *reinterpret_cast<f16x4*>(p) = o;
+  }
+};
+__device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
 
 // ---- wave / block reductions ---------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

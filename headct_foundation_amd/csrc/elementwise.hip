@@ -48,8 +48,8 @@ __global__ void mask_rank_kernel(const float* __restrict__ noise, int L, int K, 
 // =============================================================================================
 // patch gather: kept tokens only, Conv3d weight order (c, ph, pw, pd) -- patch_embedding.py:149
 // =============================================================================================
-template <typename T>
-__global__ void patch_gather_kernel(const float* __restrict__ x, const int32_t* __restrict__ ids_shuffle, int C, int S,
+template <typename TX, typename T>
+__global__ void patch_gather_kernel(const TX* __restrict__ x, const int32_t* __restrict__ ids_shuffle, int C, int S,
                                     int P, int L, int K, T* __restrict__ rows) {
   const int r = blockIdx.x;  // b*K + j
   const int b = r / K, j = r - b * K;
@@ -65,8 +65,8 @@ __global__ void patch_gather_kernel(const float* __restrict__ x, const int32_t* 
     const int pw = t % P; t /= P;
     const int ph = t % P; t /= P;
     const int c = t;
-    const float* src = x + ((((size_t)b * C + c) * S + (gh * P + ph)) * S + (gw * P + pw)) * S + gd * P + q * 4;
-    Vec4<T>::store(out + (size_t)v * 4, Vec4<float>::load(src));
+    const TX* src = x + ((((size_t)b * C + c) * S + (gh * P + ph)) * S + (gw * P + pw)) * S + gd * P + q * 4;
+    Vec4<T>::store(out + (size_t)v * 4, Vec4<TX>::load(src));
   }
 }
 
@@ -419,11 +419,11 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_tmp) {
   return (s_tmp[0] + s_tmp[1]) + (s_tmp[2] + s_tmp[3]);
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) masked_mse_kernel(const T* __restrict__ pred, const float* __restrict__ x,
+template <typename TX, typename T>
+__global__ void __launch_bounds__(256) masked_mse_kernel(const T* __restrict__ pred, const TX* __restrict__ x,
                                                          const float* __restrict__ mask, int C, int S, int P, int L,
                                                          int norm_pix, float inv_masksum, float* __restrict__ row_loss,
-                                                         T* __restrict__ dpred, const float* __restrict__ dscale) {
+                                                         T* __restrict__ dpred, const float* __restrict__ dscale, float hscale) {
   __shared__ float s_tmp[4];
   const int r = blockIdx.x;
   const int b = r / (L + 1), t = r - b * (L + 1);
@@ -445,14 +445,14 @@ __global__ void __launch_bounds__(256) masked_mse_kernel(const T* __restrict__ p
   }
   const int g = S / P;
   const int gh = l / (g * g), gw = (l / g) % g, gd = l % g;
-  const float* vol = x + (size_t)b * C * S * S * S;
+  const TX* vol = x + (size_t)b * C * S * S * S;
   auto tgt_at = [&](int k) -> float {  // patchify order (ph, pw, pd, c), c fastest -- mae.py:166-168
     const int c = k % C;
     int u = k / C;
     const int pz = u % P; u /= P;
     const int pw = u % P; u /= P;
     const int ph = u;
-    return vol[(((size_t)c * S + (gh * P + ph)) * S + (gw * P + pw)) * S + gd * P + pz];
+    return to_f32(vol[(((size_t)c * S + (gh * P + ph)) * S + (gw * P + pw)) * S + gd * P + pz]);
   };
   float mu = 0.f, rsd = 1.f;
   if (norm_pix) {
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(256) masked_mse_kernel(const T* __restrict__ p
     const float var = block_sum_256(q, s_tmp) / (float)(pd - 1);  // unbiased, mae.py:292
     rsd = 1.0f / sqrtf(var + 1.0e-6f);
   }
-  const float gscale = 2.0f * inv_masksum / (float)pd * (dscale ? *dscale : 1.0f);
+  const float gscale = 2.0f * inv_masksum / (float)pd * (dscale ? *dscale : 1.0f) * hscale;
   float sse = 0.f;
   if (C == 1) {
     for (int k = threadIdx.x * 4; k < pd; k += 1024) {
@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(256) masked_mse_kernel(const T* __restrict__ p
       const int pz = u % P; u /= P;
       const int pw = u % P; u /= P;
       const int ph = u;
-      f32x4 tv = Vec4<float>::load(vol + ((size_t)(gh * P + ph) * S + (gw * P + pw)) * S + gd * P + pz);
+      f32x4 tv = Vec4<TX>::load(vol + ((size_t)(gh * P + ph) * S + (gw * P + pw)) * S + gd * P + pz);
       tv = (tv - mu) * rsd;
       const f32x4 df = Vec4<T>::load(prow + k) - tv;
       sse += (df[0] * df[0] + df[1] * df[1]) + (df[2] * df[2] + df[3] * df[3]);
@@ -710,6 +710,47 @@ __global__ void pos_embed_interp3d_kernel(const float* __restrict__ src, int gs,
 }
 }  // namespace hct
 
+template <typename T>
+__global__ void __launch_bounds__(256) scale_unless_one_kernel(T* __restrict__ buf, int64_t n4, const float* __restrict__ scale) {
+  const float sc = *scale;
+  if (sc == 1.0f) return;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    Vec4<T>::store(buf + i * 4, Vec4<T>::load(buf + i * 4) * sc);
+}
+
+namespace hct {
+int scale_unless_one(void* buf, int dtype, int64_t n, const float* scale, hipStream_t s) {
+  HCT_REQUIRE(n % 4 == 0 && scale, "scale_unless_one: n %% 4 != 0 or null scale");
+  const int blocks = (int)std::min<int64_t>(2048, (n / 4 + 255) / 256);
+  if (blocks == 0) return 0;
+  HCT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(scale_unless_one_kernel<T>, dim3(blocks), dim3(256), 0, s, (T*)buf, n / 4, scale));
+  HCT_CHECK_LAUNCH("scale_unless_one");
+  return 0;
+}
+
+int masked_mse_launch(const void* pred, int pred_dtype, const void* x, int x_dtype, const float* mask, int B, int C, int S, int P,
+                      int norm_pix, float mask_sum, float* row_loss, float* loss, void* dpred, const float* dpred_scale,
+                      float host_scale, hipStream_t s) {
+  HCT_REQUIRE(P % 4 == 0 && S % P == 0 && mask_sum > 0.f, "hct_masked_mse: bad geometry S=%d P=%d mask_sum=%f", S, P, mask_sum);
+  HCT_REQUIRE(x_dtype == HCT_F32 || x_dtype == HCT_F16, "hct_masked_mse: volumes are fp32 or fp16");
+  const int g = S / P, L = g * g * g;
+  const int pd = P * P * P * C;
+  HCT_REQUIRE(pd % 4 == 0, "hct_masked_mse: patch dim %% 4 != 0");
+  const float inv = 1.0f / mask_sum;
+  if (x_dtype == HCT_F16) {
+    HCT_DISPATCH_DTYPE(pred_dtype, T,
+                       hipLaunchKernelGGL((masked_mse_kernel<f16, T>), dim3(B * (L + 1)), dim3(256), 0, s, (const T*)pred, (const f16*)x, mask,
+                                          C, S, P, L, norm_pix, inv, loss ? row_loss : nullptr, (T*)dpred, dpred_scale, host_scale));
+  } else
+  HCT_DISPATCH_DTYPE(pred_dtype, T,
+                     hipLaunchKernelGGL((masked_mse_kernel<float, T>), dim3(B * (L + 1)), dim3(256), 0, s, (const T*)pred, (const float*)x, mask,
+                                        C, S, P, L, norm_pix, inv, loss ? row_loss : nullptr, (T*)dpred, dpred_scale, host_scale));
+  if (loss) hipLaunchKernelGGL(loss_fold_kernel, dim3(1), dim3(256), 0, s, row_loss, B * L, inv, loss);
+  HCT_CHECK_LAUNCH("hct_masked_mse");
+  return 0;
+}
+}  // namespace hct
+
 extern "C" {
 
 const char* hct_last_error_string(void) { return g_err; }
@@ -725,12 +766,18 @@ int hct_mask_rank(const float* noise, int B, int L, int K, int32_t* ids_restore,
   return 0;
 }
 
-int hct_patch_gather(const float* x, const int32_t* ids_shuffle, int B, int C, int S, int P, int L, int K, void* rows,
+int hct_patch_gather(const void* x, int x_dtype, const int32_t* ids_shuffle, int B, int C, int S, int P, int L, int K, void* rows,
                      int rows_dtype, void* stream) {
   HCT_REQUIRE(P % 4 == 0 && S % P == 0 && (S / P) * (S / P) * (S / P) == L, "hct_patch_gather: bad geometry S=%d P=%d L=%d", S, P, L);
+  HCT_REQUIRE(x_dtype == HCT_F32 || x_dtype == HCT_F16, "hct_patch_gather: volumes are fp32 or fp16");
   if (B * K == 0) return 0;
+  if (x_dtype == HCT_F16) {
+    HCT_DISPATCH_DTYPE(rows_dtype, T,
+                       hipLaunchKernelGGL((patch_gather_kernel<f16, T>), dim3(B * K), dim3(256), 0, (hipStream_t)stream, (const f16*)x,
+                                          ids_shuffle, C, S, P, L, K, (T*)rows));
+  } else
   HCT_DISPATCH_DTYPE(rows_dtype, T,
-                     hipLaunchKernelGGL(patch_gather_kernel<T>, dim3(B * K), dim3(256), 0, (hipStream_t)stream, x,
+                     hipLaunchKernelGGL((patch_gather_kernel<float, T>), dim3(B * K), dim3(256), 0, (hipStream_t)stream, (const float*)x,
                                         ids_shuffle, C, S, P, L, K, (T*)rows));
   HCT_CHECK_LAUNCH("hct_patch_gather");
   return 0;
@@ -856,21 +903,11 @@ int hct_decoder_assemble_bwd(const float* dy, const int32_t* ids_restore, const 
   return 0;
 }
 
-int hct_masked_mse(const void* pred, int pred_dtype, const float* x, const float* mask, int B, int C, int S, int P,
+int hct_masked_mse(const void* pred, int pred_dtype, const void* x, int x_dtype, const float* mask, int B, int C, int S, int P,
                    int norm_pix, float mask_sum, float* row_loss, float* loss, void* dpred, const float* dpred_scale,
                    void* stream) {
-  HCT_REQUIRE(P % 4 == 0 && S % P == 0 && mask_sum > 0.f, "hct_masked_mse: bad geometry S=%d P=%d mask_sum=%f", S, P, mask_sum);
-  const int g = S / P, L = g * g * g;
-  const int pd = P * P * P * C;
-  HCT_REQUIRE(pd % 4 == 0, "hct_masked_mse: patch dim %% 4 != 0");
-  hipStream_t s = (hipStream_t)stream;
-  const float inv = 1.0f / mask_sum;
-  HCT_DISPATCH_DTYPE(pred_dtype, T,
-                     hipLaunchKernelGGL(masked_mse_kernel<T>, dim3(B * (L + 1)), dim3(256), 0, s, (const T*)pred, x, mask,
-                                        C, S, P, L, norm_pix, inv, loss ? row_loss : nullptr, (T*)dpred, dpred_scale));
-  if (loss) hipLaunchKernelGGL(loss_fold_kernel, dim3(1), dim3(256), 0, s, row_loss, B * L, inv, loss);
-  HCT_CHECK_LAUNCH("hct_masked_mse");
-  return 0;
+  return masked_mse_launch(pred, pred_dtype, x, x_dtype, mask, B, C, S, P, norm_pix, mask_sum, row_loss, loss, dpred, dpred_scale, 1.0f,
+                           (hipStream_t)stream);
 }
 
 int hct_unpatchify(const void* pred, int pred_dtype, int has_cls_row, int B, int C, int S, int P, float* vol,

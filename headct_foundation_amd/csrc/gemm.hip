@@ -1479,8 +1479,13 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
     return hct_colsum(a->C, a->c_dtype, a->M, a->N, a->ldc, a->colsum_out, workspace, workspace_bytes, stream);
   };
   const double flops = 2.0 * a->M * a->N * a->K;
+  // algorithmic bytes: each operand read once, each output written once (SURVEY 8d secondary report)
+  const double mn = (double)a->M * a->N;
+  const double bytes = (double)a->M * a->K * dtype_size(a->a_dtype) + (double)a->N * a->K * dtype_size(a->b_dtype) +
+                       mn * dtype_size(a->c_dtype) + (a->residual ? mn * 4 : 0.0) + (a->aux ? mn * dtype_size(a->aux_dtype) : 0.0) +
+                       (a->C2 ? mn * dtype_size(a->c2_dtype) : 0.0);
   if (path == PATH_NT) {
-    ProfScope ps(PROF_GEMM_NT, flops, s);
+    ProfScope ps(PROF_GEMM_NT, flops, s, bytes);
     const int tiles256 = ((a->M + 255) / 256) * ((a->N + 255) / 256);
     const bool ok256 = a->K % 64 == 0 && a->K >= 128;
     const bool big = ok256 && (g_nt_variant == 256 || g_nt_variant == 4 || g_nt_variant == 0);
@@ -1540,7 +1545,7 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
     return finish_colsum(false);
   }
   if (path == PATH_TN && tn256_ok(a)) {
-    ProfScope ps(PROF_GEMM_TN, flops, s);
+    ProfScope ps(PROF_GEMM_TN, flops, s, bytes);
     int splits, r_chunk;
     tn256_split(a, splits, r_chunk);
     const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256) * splits;
@@ -1563,7 +1568,7 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
     return 0;
   }
   if (path == PATH_TN) {
-    ProfScope ps(PROF_GEMM_TN, flops, s);
+    ProfScope ps(PROF_GEMM_TN, flops, s, bytes);
     int splits, r_chunk;
     tn_split(a, splits, r_chunk);
     const int tiles = ((a->M + 127) / 128) * ((a->N + 127) / 128);
@@ -1586,7 +1591,7 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
     return 0;
   }
   // generic
-  ProfScope ps(PROF_GEMM_GENERIC, flops, s);
+  ProfScope ps(PROF_GEMM_GENERIC, flops, s, bytes);
   const int64_t sam = a->transA ? 1 : a->lda, sak = a->transA ? a->lda : 1;
   const int64_t sbk = a->transB ? 1 : a->ldb, sbn = a->transB ? a->ldb : 1;
   const int vec_ok = epilogue_vec_ok(a) ? 1 : 0;

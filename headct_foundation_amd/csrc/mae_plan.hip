@@ -59,6 +59,7 @@ struct hct_mae_plan {
   bf16* params_bf16_t = nullptr;
   unsigned char* ws = nullptr;
   bool fwd_done = false;
+  bool dpred_done = false;  // the last forward also wrote d(loss)/d(pred) (training forward)
   const float* dloss = nullptr;
 
   size_t esz() const { return dtype_size(dt); }
@@ -324,7 +325,7 @@ hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int comput
   p->B = batch; p->dt = compute_dtype;
   p->g = c->input_size / c->patch_size;
   p->L = p->g * p->g * p->g;
-  p->K = (int)((double)p->L * (1.0 - (double)c->mask_ratio));  // int(L * (1 - mask_ratio)), mae.py:205
+  p->K = (int)((double)p->L * (1.0 - c->mask_ratio));  // int(L * (1 - mask_ratio)) in double, as Python evaluates mae.py:205
   p->pd = c->in_chans * c->patch_size * c->patch_size * c->patch_size;
   p->Ne = p->K + 1; p->Nd = p->L + 1;
   p->Me = batch * p->Ne; p->Md = batch * p->Nd;
@@ -455,6 +456,7 @@ int hct_mae_plan_param_info(const hct_mae_plan* p, int index, hct_param_info* ou
 int64_t hct_mae_plan_param_elems(const hct_mae_plan* p) { return p->param_elems; }
 int64_t hct_mae_plan_bf16_t_elems(const hct_mae_plan* p) { return p->bf16t_elems; }
 size_t hct_mae_plan_workspace_bytes(const hct_mae_plan* p) { return p->ws_bytes; }
+int hct_mae_plan_len_keep(const hct_mae_plan* p) { return p ? p->K : -1; }
 
 int hct_mae_plan_bind(hct_mae_plan* p, float* params, float* grads, void* params_bf16, void* params_bf16_t, void* workspace,
                       size_t workspace_bytes) {
@@ -493,8 +495,9 @@ int hct_mae_refresh_weights(hct_mae_plan* p, int with_plain, void* stream) {
   return 0;
 }
 
-int hct_mae_forward(hct_mae_plan* p, const float* x, const float* noise, float* loss, void* stream) {
+int hct_mae_forward(hct_mae_plan* p, const void* x, int x_dtype, const float* noise, float* loss, float grad_scale, void* stream) {
   HCT_REQUIRE(p && p->ws && x && noise && loss, "hct_mae_forward: plan not bound or null argument");
+  HCT_REQUIRE(x_dtype == HCT_F32 || x_dtype == HCT_F16, "hct_mae_forward: volumes are fp32 or fp16");
   hipStream_t s = (hipStream_t)stream;
   unsigned char* ws = p->ws;
   const hct_mae_config& c = p->cfg;
@@ -503,7 +506,7 @@ int hct_mae_forward(hct_mae_plan* p, const float* x, const float* noise, float* 
   int32_t* ids_shuffle = (int32_t*)(ws + p->a_ids_shuffle);
   float* mask = (float*)(ws + p->a_mask);
   RC(hct_mask_rank(noise, B, p->L, p->K, ids_restore, ids_shuffle, mask, s));
-  RC(hct_patch_gather(x, ids_shuffle, B, c.in_chans, c.input_size, c.patch_size, p->L, p->K, ws + p->a_patches, p->dt, s));
+  RC(hct_patch_gather(x, x_dtype, ids_shuffle, B, c.in_chans, c.input_size, c.patch_size, p->L, p->K, ws + p->a_patches, p->dt, s));
   RC(linear_fwd(p, ws + p->a_patches, B * p->K, p->pd, p->p_pe_w, p->p_pe_b, p->D, ws + p->a_tok, p->dt, HCT_ACT_NONE, nullptr, nullptr, s));
   RC(hct_encoder_assemble_fwd(ws + p->a_tok, p->dt, p->pf(p->p_cls), p->pf(p->p_pos), ids_shuffle, B, p->L, p->K, p->D, (float*)(ws + p->h_enc[0]), s));
   for (int i = 0; i < c.encoder_depth; ++i)
@@ -518,9 +521,15 @@ int hct_mae_forward(hct_mae_plan* p, const float* x, const float* noise, float* 
   RC(hct_layernorm_fwd((const float*)(ws + p->h_dec[c.decoder_depth]), p->pf(p->p_dnorm_w), p->pf(p->p_dnorm_b), p->Md, p->Dd, 1e-5f,
                        ws + p->a_ynorm, p->dt, (float*)(ws + p->a_yn_mean), (float*)(ws + p->a_yn_rstd), s));
   RC(linear_fwd(p, ws + p->a_ynorm, p->Md, p->Dd, p->p_pred_w, p->p_pred_b, p->pd, ws + p->a_pred, p->dt, HCT_ACT_NONE, nullptr, nullptr, s));
-  RC(hct_masked_mse(ws + p->a_pred, p->dt, x, mask, B, c.in_chans, c.input_size, c.patch_size, c.norm_pix_loss,
-                    (float)((int64_t)B * (p->L - p->K)), (float*)(ws + p->a_row_loss), loss, nullptr, nullptr, s));
+  // One pass over the volume and the prediction gives the loss and, in a training forward (grad_scale != 0), the seed of
+  // the backward d(loss)/d(pred) * grad_scale as well (grad_scale = the data-parallel 1 / world_size, known on the host);
+  // the incoming dLoss is a device scalar that is only known in the backward and is applied there if it is not 1.
+  const bool train = grad_scale != 0.0f;
+  RC(masked_mse_launch(ws + p->a_pred, p->dt, x, x_dtype, mask, B, c.in_chans, c.input_size, c.patch_size, c.norm_pix_loss,
+                       (float)((int64_t)B * (p->L - p->K)), (float*)(ws + p->a_row_loss), loss, train ? ws + p->a_dpred : nullptr, nullptr,
+                       train ? grad_scale : 1.0f, s));
   p->fwd_done = true;
+  p->dpred_done = train;
   return 0;
 }
 
@@ -538,7 +547,7 @@ int hct_mae_backward_stage_range(const hct_mae_plan* p, int stage, int64_t* begi
   return 0;
 }
 
-int hct_mae_backward_stage(hct_mae_plan* p, int stage, const float* x, void* stream) {
+int hct_mae_backward_stage(hct_mae_plan* p, int stage, void* stream) {
   HCT_REQUIRE(p && p->ws && p->grads, "hct_mae_backward_stage: plan not bound (or no gradient buffer)");
   if (!p->fwd_done) { set_error("hct_mae_backward_stage: forward has not run"); return HCT_E_STATE; }
   hipStream_t s = (hipStream_t)stream;
@@ -551,9 +560,8 @@ int hct_mae_backward_stage(hct_mae_plan* p, int stage, const float* x, void* str
   void* dx = ws + p->s_dx;
   void* small = ws + p->s_small;
   if (stage == 0) {  // loss seed -> decoder_pred -> decoder_norm
-    HCT_REQUIRE(x, "hct_mae_backward_stage: stage 0 needs the input volume");
-    RC(hct_masked_mse(ws + p->a_pred, p->dt, x, (const float*)(ws + p->a_mask), B, c.in_chans, c.input_size, c.patch_size, c.norm_pix_loss,
-                      (float)((int64_t)B * (p->L - p->K)), nullptr, nullptr, ws + p->a_dpred, p->dloss, s));
+    if (!p->dpred_done) { set_error("hct_mae_backward_stage: the last forward ran without grad_scale (inference forward)"); return HCT_E_STATE; }
+    if (p->dloss) RC(scale_unless_one(ws + p->a_dpred, p->dt, (int64_t)p->Md * p->pd, p->dloss, s));
     RC(linear_wgrad(p, ws + p->a_dpred, ws + p->a_ynorm, p->Md, p->pd, p->Dd, p->p_pred_w, p->p_pred_b, s));
     RC(linear_dgrad(p, ws + p->a_dpred, p->Md, p->pd, p->p_pred_w, p->Dd, dx, HCT_ACT_NONE, nullptr, s));
     RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + p->h_dec[nd]), (const float*)(ws + p->a_yn_mean), (const float*)(ws + p->a_yn_rstd),

@@ -6,8 +6,8 @@ enum { PROF_GEMM_NT = 0, PROF_GEMM_TN = 1, PROF_GEMM_GENERIC = 2, PROF_ATTN_FWD 
        PROF_OPTIM = 6 };
 bool prof_enabled();
 struct ProfScope {
-  ProfScope(int id, double work, hipStream_t s);
+  ProfScope(int id, double work, hipStream_t s, double bytes = 0.0);
   ~ProfScope();
-  int id_; double work_; hipStream_t s_; bool on_; void* a_ = nullptr; void* b_ = nullptr;
+  int id_; double work_; double bytes_ = 0.0; hipStream_t s_; bool on_; void* a_ = nullptr; void* b_ = nullptr;
 };
 }  // namespace hct

@@ -8,7 +8,7 @@
 
 namespace hct {
 
-struct ProfRec { int id; hipEvent_t a, b; double work; };
+struct ProfRec { int id; hipEvent_t a, b; double work, bytes; };
 static unsigned g_prof_mask = 0;  // bit i = kernel class i is timed
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -23,7 +23,7 @@ static hipEvent_t take_event() {
   return e;
 }
 
-ProfScope::ProfScope(int id, double work, hipStream_t s) : id_(id), work_(work), s_(s), on_((g_prof_mask >> id) & 1u) {
+ProfScope::ProfScope(int id, double work, hipStream_t s, double bytes) : id_(id), work_(work), bytes_(bytes), s_(s), on_((g_prof_mask >> id) & 1u) {
   if (!on_) return;
   std::lock_guard<std::mutex> lk(g_mu);
   a_ = take_event();
@@ -34,7 +34,7 @@ ProfScope::~ProfScope() {
   if (!on_) return;
   hipEventRecord((hipEvent_t)b_, s_);
   std::lock_guard<std::mutex> lk(g_mu);
-  g_recs.push_back(ProfRec{id_, (hipEvent_t)a_, (hipEvent_t)b_, work_});
+  g_recs.push_back(ProfRec{id_, (hipEvent_t)a_, (hipEvent_t)b_, work_, bytes_});
 }
 
 }  // namespace hct
@@ -68,6 +68,16 @@ int hct_prof_read(int id, double* total_ms, int64_t* launches, double* work) {
   if (total_ms) *total_ms = ms;
   if (launches) *launches = n;
   if (work) *work = w;
+  return 0;
+}
+
+// Sum of the algorithmic bytes (operands read once + outputs written once) the recorded launches of class `id` declared.
+int hct_prof_read_bytes(int id, double* bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  double b = 0;
+  for (auto& r : g_recs)
+    if (r.id == id) b += r.bytes;
+  if (bytes) *bytes = b;
   return 0;
 }
 

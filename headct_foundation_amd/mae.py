@@ -92,9 +92,12 @@ class _Plan:
         lib = _lib.load()
         self.lib = lib
         self.batch = batch
+        self.serial = 0
         self.handle = lib.hct_mae_plan_create(C.byref(model._ccfg), batch, model._dt)
         if not self.handle:
             raise HctError("hct_mae_plan_create: " + lib.hct_last_error_string().decode())
+        if lib.hct_mae_plan_len_keep(self.handle) != model.len_keep:
+            raise HctError(f"native plan keeps {lib.hct_mae_plan_len_keep(self.handle)} patches, the module {model.len_keep}")
         nbytes = lib.hct_mae_plan_workspace_bytes(self.handle)
         dev = model._flat.device
         self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
@@ -137,19 +140,26 @@ class _MAEFunction(torch.autograd.Function):
     writes straight into the model's flat gradient buffer (`p.grad` are views of it)."""
 
     @staticmethod
-    def forward(ctx, anchor, model, x, noise):
+    def forward(ctx, anchor, model, x, noise, train):
         plan = model._plan_for(x.shape[0])
         st = _lib.stream_ptr()
         model._ensure_weights_fresh(plan, st)
-        _lib.check(plan.lib.hct_mae_forward(plan.handle, x.data_ptr(), noise.data_ptr(), plan.loss.data_ptr(), st), "hct_mae_forward")
-        ctx.model, ctx.plan, ctx.x = model, plan, x
+        # training forward: the loss pass also leaves d(loss)/d(pred) (scaled by 1/world under data parallelism) for the backward
+        xdt = _lib.HCT_F16 if x.dtype == torch.float16 else HCT_F32
+        _lib.check(plan.lib.hct_mae_forward(plan.handle, x.data_ptr(), xdt, noise.data_ptr(), plan.loss.data_ptr(),
+                                            float(model._grad_prescale) if train else 0.0, st), "hct_mae_forward")
+        plan.serial += 1  # the plan's one activation workspace now belongs to this forward
+        ctx.model, ctx.plan, ctx.x, ctx.serial = model, plan, x, plan.serial
         return plan.loss[0].clone()
 
     @staticmethod
     def backward(ctx, grad_out):
         model, plan, x = ctx.model, ctx.plan, ctx.x
+        if plan.serial != ctx.serial:
+            raise HctError("backward of a stale forward: another forward at the same batch size has overwritten the activation "
+                           "workspace (run loss.backward() before the next model(...) call, e.g. before an eval pass)")
         model._run_backward(plan, x, grad_out)
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 class MaskedAutoencoderViT(nn.Module):
@@ -322,6 +332,7 @@ class MaskedAutoencoderViT(nn.Module):
         self._seg_names = [n for n, *_ in sorted(layout, key=lambda t: t[1])]
         self._plans = {}
         self._weights_version += 1
+        self._plain_fresh = False
         self._named_cache = named
 
     def _apply(self, fn, recurse=True):
@@ -334,6 +345,7 @@ class MaskedAutoencoderViT(nn.Module):
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         out = super().load_state_dict(state_dict, strict=strict, assign=False)
         self._weights_version += 1
+        self._plain_fresh = False  # the bf16 copies written by the last optimizer step no longer match the masters
         return out
 
     def mark_weights_updated(self, plain_bf16_fresh: bool = False) -> None:
@@ -391,27 +403,28 @@ class MaskedAutoencoderViT(nn.Module):
     def _run_backward(self, plan: _Plan, x: torch.Tensor, grad_out: torch.Tensor) -> None:
         lib = plan.lib
         st = _lib.stream_ptr()
-        prev = None
-        any_grad = any(p.grad is not None for p in self.parameters())
-        accumulate = any_grad and not self._grad_overwrite
-        if accumulate:
-            prev = self._flat_grad.clone()
+        # a second backward without zero_grad() adds to what is there (torch semantics).  The native stages overwrite the
+        # flat buffer, so the earlier gradient is parked and added back at the end -- AFTER the data-parallel reduction of
+        # the fresh gradient (every backward is reduced, as torch's DDP does; the parked part is already the mean).
+        parked = None
+        if not self._grad_overwrite and any(p.grad is not None for p in self.parameters()):
+            self._attach_grads()  # a foreign / preset .grad tensor is folded into the flat buffer first
+            parked = self._flat_grad.clone()
+        # the data-parallel mean (1 / world) is already folded into the seed the forward wrote (ddp.py sets _grad_prescale)
         g = grad_out.detach().to(dtype=torch.float32).reshape(1).contiguous()
-        if self._grad_prescale != 1.0:  # data-parallel mean folded into the backward seed (ddp.py)
-            g = g * self._grad_prescale
         _lib.check(lib.hct_mae_set_loss_grad(plan.handle, g.data_ptr()), "hct_mae_set_loss_grad")
         for s in range(plan.nstages):
-            _lib.check(lib.hct_mae_backward_stage(plan.handle, s, x.data_ptr(), st), f"hct_mae_backward_stage({s})")
-            if self._bucket_hook is not None and not accumulate:
+            _lib.check(lib.hct_mae_backward_stage(plan.handle, s, st), f"hct_mae_backward_stage({s})")
+            if self._bucket_hook is not None:
                 b, e = plan.stage_ranges[s]
                 self._bucket_hook(s, b, e)
         self._keep_alive = g
-        if prev is not None:
-            self._flat_grad.add_(prev)
+        if self._post_backward_hook is not None:
+            self._post_backward_hook()  # data parallel: the compute stream now waits for the collectives
+        if parked is not None:
+            self._flat_grad.add_(parked)
         self._attach_grads()
         self._grad_overwrite = False
-        if self._post_backward_hook is not None:
-            self._post_backward_hook()
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         super().zero_grad(set_to_none=set_to_none)
@@ -427,14 +440,17 @@ class MaskedAutoencoderViT(nn.Module):
         expect = (B, self.in_chans) + tuple(self.input_size)
         if tuple(x.shape) != expect:
             raise HctError(f"input shape {tuple(x.shape)} != {expect} (run-time pos-embed interpolation is out of scope)")
-        x = x.contiguous().float()
+        # fp16 volumes (the persistent cache's storage type, transforms.py:171-178) are consumed as they are: the patch gather
+        # and the loss read them directly, which halves the two input passes of a step; anything else is taken as fp32
+        x = x.contiguous() if x.dtype == torch.float16 else x.contiguous().float()
         if noise is None:
             noise = torch.rand(B, self.num_patches, device=x.device)  # mae.py:206
         noise = noise.contiguous().float()
         # a freshly zero_grad()-ed model (all .grad None) means the next backward overwrites
         if all(p.grad is None for p in self.parameters()):
             self._grad_overwrite = True
-        loss = _MAEFunction.apply(self.cls_token, self, x, noise)
+        # grad mode is read here: inside autograd.Function.forward it is always off
+        loss = _MAEFunction.apply(self.cls_token, self, x, noise, torch.is_grad_enabled())
         return loss, None, None
 
     def activation(self, name: str, batch: int) -> torch.Tensor:

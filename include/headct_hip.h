@@ -92,7 +92,7 @@ int hct_mask_rank(const float* noise, int B, int L, int K, int32_t* ids_restore,
  * Patch gather (im2col of the stride==kernel Conv3d, kept tokens only; patch_embedding.py:149-152
  * + mae.py:212).   x [B,C,S,S,S] fp32 -> rows [B*K, C*P^3] in Conv3d weight order (c,ph,pw,pd).
  * ------------------------------------------------------------------------------------------ */
-int hct_patch_gather(const float* x, const int32_t* ids_shuffle, int B, int C, int S, int P, int L, int K,
+int hct_patch_gather(const void* x, int x_dtype /* HCT_F32 | HCT_F16 */, const int32_t* ids_shuffle, int B, int C, int S, int P, int L, int K,
                      void* rows, int rows_dtype, void* stream);
 
 /* Encoder input assembly: h0[b,0,:] = cls;  h0[b,1+j,:] = tok[b*K+j,:] + pos[ids_keep[b,j],:]
@@ -156,7 +156,7 @@ int hct_decoder_assemble_bwd(const float* dy, const int32_t* ids_restore, const 
  *   norm_pix: per-patch (t-mean)/sqrt(var_unbiased+1e-6) target (mae.py:290-293).
  *   mask_sum = sum(mask) (= B*(L-K) for masks from hct_mask_rank); row_loss: workspace of B*L floats.
  * ------------------------------------------------------------------------------------------ */
-int hct_masked_mse(const void* pred, int pred_dtype, const float* x, const float* mask, int B, int C, int S,
+int hct_masked_mse(const void* pred, int pred_dtype, const void* x, int x_dtype /* HCT_F32 | HCT_F16 */, const float* mask, int B, int C, int S,
                    int P, int norm_pix, float mask_sum, float* row_loss, float* loss, void* dpred,
                    const float* dpred_scale, void* stream);
 /* reconstructed voxels: unpatchify (mae.py:172-192). pred rows [B, L(+1 if has_cls_row), pd] -> [B,C,S,S,S] fp32 */
@@ -256,7 +256,7 @@ int hct_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_s
  * ------------------------------------------------------------------------------------------ */
 typedef struct hct_mae_config {
   int input_size, patch_size, in_chans;
-  float mask_ratio;
+  double mask_ratio; /* double: len_keep = (int)(L * (1 - mask_ratio)) must round as the reference's Python float does (mae.py:205) */
   int pos_embed; /* 0 none, 1 learnable, 2 sincos (same storage; init differs on the host) */
   int encoder_depth, encoder_embed_dim, encoder_mlp_dim, encoder_num_heads;
   int decoder_depth, decoder_embed_dim, decoder_mlp_dim, decoder_num_heads;
@@ -284,22 +284,27 @@ int hct_mae_plan_param_info(const hct_mae_plan*, int index, hct_param_info* out)
 int64_t hct_mae_plan_param_elems(const hct_mae_plan*);     /* flat fp32 params / grads length (padded) */
 int64_t hct_mae_plan_bf16_t_elems(const hct_mae_plan*);    /* transposed-bf16 weight buffer length      */
 size_t hct_mae_plan_workspace_bytes(const hct_mae_plan*);  /* activations + scratch                      */
+int hct_mae_plan_len_keep(const hct_mae_plan*);            /* visible patches per volume = int(L * (1 - mask_ratio)) */
 /* bind caller-owned device buffers. params_bf16 / params_bf16_t may be NULL in HCT_F32 mode. */
 int hct_mae_plan_bind(hct_mae_plan*, float* params, float* grads, void* params_bf16, void* params_bf16_t,
                       void* workspace, size_t workspace_bytes);
 /* refresh bf16 + transposed-bf16 working copies from the fp32 master weights (after load / optimizer step).
  * with_plain = 0 skips the plain bf16 copy (hct_adamw_step already wrote it). */
 int hct_mae_refresh_weights(hct_mae_plan*, int with_plain, void* stream);
-/* forward: x [B,C,S,S,S] fp32, noise [B,L] fp32 -> *loss (device fp32). Saves activations in the workspace. */
-int hct_mae_forward(hct_mae_plan*, const float* x, const float* noise, float* loss, void* stream);
-/* device pointer to the scalar dLoss that seeds the backward (NULL = 1.0). */
+/* forward: x [B,C,S,S,S] of x_dtype (HCT_F32, or HCT_F16 = the persistent cache's storage type, transforms.py:171-178),
+ * noise [B,L] fp32 -> *loss (device fp32).  Saves activations in the workspace.
+ * grad_scale != 0: training forward -- the loss pass also writes the backward's seed d(loss)/d(pred) * grad_scale (the
+ * volume and the prediction are read once per step); grad_scale = 1 / world_size under data parallelism, else 1.
+ * grad_scale == 0: inference forward (no backward may follow). */
+int hct_mae_forward(hct_mae_plan*, const void* x, int x_dtype, const float* noise, float* loss, float grad_scale, void* stream);
+/* device pointer to the scalar dLoss that multiplies the backward's seed (NULL = 1.0; a value of 1.0 costs nothing). */
 int hct_mae_set_loss_grad(hct_mae_plan*, const float* dloss);
 /* backward in stages so the host can launch the per-bucket gradient all-reduce between them:
  * stage 0 .. hct_mae_num_backward_stages()-1, in order; each stage finishes the gradients of the
  * parameter range reported by hct_mae_backward_stage_range (element offsets into the flat buffer). */
 int hct_mae_num_backward_stages(const hct_mae_plan*);
 int hct_mae_backward_stage_range(const hct_mae_plan*, int stage, int64_t* begin, int64_t* end);
-int hct_mae_backward_stage(hct_mae_plan*, int stage, const float* x, void* stream);
+int hct_mae_backward_stage(hct_mae_plan*, int stage, void* stream);
 /* named activation lookup for parity tests: returns device pointer + shape/dtype, or NULL. */
 const void* hct_mae_plan_activation(const hct_mae_plan*, const char* name, int64_t* rows, int64_t* cols, int* dtype);
 
@@ -312,6 +317,7 @@ const void* hct_mae_plan_activation(const hct_mae_plan*, const char* name, int64
 void hct_prof_enable(int mask); /* bit i enables kernel class i; 0 = off */
 void hct_prof_reset(void);
 int hct_prof_read(int id, double* total_ms, int64_t* launches, double* work);
+int hct_prof_read_bytes(int id, double* bytes); /* algorithmic bytes (operands read once + outputs written once) of those launches */
 /* testing hook: route bf16 attention through the fp32-math kernels */
 void hct_debug_force_simple_attention(int on);
 /* testing hook: force the NT GEMM tile variant (0 auto, 128, 256) */

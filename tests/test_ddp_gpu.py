@@ -62,6 +62,26 @@ def _worker(rank, world, port, dtype, cap_mb, out):
         tol = 2e-4 if dtype == "fp32" else 2e-2
         worst = max((rel_err(g[k], gs[k]), k) for k in g if not k.endswith("qkv.bias"))
         assert worst[0] < tol, worst
+        # gradient accumulation: a second backward without zero_grad() is reduced as well (every backward is, as in torch's
+        # DDP) and lands on top of the already averaged first one -> identical on both ranks, equal to the single-process sum
+        xs2 = [O.make_volume(cfg, B, 30 + r).to(dev) for r in range(world)]
+        ns2 = [O.make_noise(cfg, B, 30 + r).to(dev) for r in range(world)]
+        ddp(xs2[rank], noise=ns2[rank])[0].backward()
+        single(torch.cat(xs2), noise=torch.cat(ns2))[0].backward()
+        torch.cuda.synchronize()
+        g2, gs2 = grads_by_name(model), grads_by_name(single)
+        worst2 = max((rel_err(g2[k], gs2[k]), k) for k in g2 if not k.endswith("qkv.bias"))
+        assert worst2[0] < tol, worst2
+        both = [torch.empty_like(model._flat_grad) for _ in range(world)]
+        dist.all_gather(both, model._flat_grad.detach().clone())
+        assert torch.equal(both[0], both[1]), "accumulated gradients differ between ranks"
+        # zero_grad(set_to_none=False) from a foreign optimizer keeps the .grad tensors: the next backward still reduces
+        torch.optim.SGD(model.parameters(), lr=0.0).zero_grad(set_to_none=False)
+        ddp(xs[rank], noise=ns[rank])[0].backward()
+        torch.cuda.synchronize()
+        g3 = grads_by_name(model)
+        worst3 = max((rel_err(g3[k], gs[k]), k) for k in g3 if not k.endswith("qkv.bias"))
+        assert worst3[0] < tol, worst3
         clip_gradients(ddp, 3.0)
         opt.step()
         torch.cuda.synchronize()

@@ -140,3 +140,21 @@ def test_optimizer_state_dict_is_torch_adamw_compatible(lib):
     g, gr = sd["param_groups"][0], ref.state_dict()["param_groups"][0]
     assert g["params"] == gr["params"] and g["lr"] == gr["lr"] and g["betas"] == gr["betas"] and g["weight_decay"] == gr["weight_decay"]
     assert g["eps"] == gr["eps"] == 1e-8
+
+
+@pytest.mark.parametrize("input_size,patch,ratio", [(80, 8, 0.6), (80, 8, 0.9), (40, 8, 0.6), (96, 16, 0.75), (64, 16, 0.5),
+                                                    (80, 8, 0.3), (80, 8, 0.7), (48, 8, 0.9)])
+def test_plan_keeps_as_many_patches_as_python_does(lib, input_size, patch, ratio):
+    """int(L * (1 - mask_ratio)) is evaluated in double on both sides of the C ABI (a float32 ratio gives 100 instead of
+    99 kept patches at L=1000, ratio 0.9, and 399 instead of 400 at 0.6)."""
+    from headct_foundation_amd import MaskedAutoencoderViT
+    m = MaskedAutoencoderViT(input_size=input_size, patch_size=patch, mask_ratio=ratio, encoder_depth=1, encoder_embed_dim=48,
+                             encoder_mlp_dim=96, encoder_num_heads=2, decoder_depth=1, decoder_embed_dim=48, decoder_mlp_dim=96,
+                             decoder_num_heads=2, pos_embed="sincos")
+    L = (input_size // patch) ** 3
+    assert m.len_keep == int(L * (1 - ratio))
+    h = lib.hct_mae_plan_create(C.byref(m._ccfg), 2, m._dt)
+    try:
+        assert lib.hct_mae_plan_len_keep(h) == m.len_keep
+    finally:
+        lib.hct_mae_plan_destroy(h)

@@ -291,3 +291,22 @@ def test_other_mask_ratios_vs_oracle(lib, cuda, mask_ratio):
     grads = grads_by_name(model)
     worst = max((rel_err(grads[k], o_grads[k]), k) for k in grads if not k.endswith("qkv.bias"))
     assert worst[0] < 1e-3, worst
+
+
+@pytest.mark.parametrize("mask_ratio,kept", [(0.6, 400), (0.9, 99)])
+def test_thousand_patch_grid_keeps_the_reference_count(lib, cuda, mask_ratio, kept):
+    """L = 1000 (80^3 volume, 8^3 patches): int(1000 * (1 - 0.9)) = 99 and int(1000 * (1 - 0.6)) = 400 in Python doubles; a
+    float32 ratio across the C ABI gave 100 / 399.  Loss, mask and gradients against the oracle, fp32, rel 1e-3."""
+    import dataclasses
+    cfg = dataclasses.replace(O.CONFIGS["micro"], input_size=80, patch_size=8, mask_ratio=mask_ratio, encoder_depth=1)
+    assert int(cfg.num_patches * (1 - mask_ratio)) == kept
+    params = O.make_params(cfg, 5)
+    x, noise = O.make_volume(cfg, 1, 5), O.make_noise(cfg, 1, 5)
+    o_loss, o_pred, o_mask, o_grads, _ = O.forward_backward(cfg, params, x, noise)
+    model, loss = _run_hip(cfg, params, x, noise, cuda, "fp32")
+    assert model.len_keep == kept and int(o_mask.sum()) == cfg.num_patches - kept
+    assert torch.equal(model.last_mask(1).cpu(), o_mask)
+    assert abs(loss - float(o_loss)) / abs(float(o_loss)) < 1e-3
+    grads = grads_by_name(model)
+    worst = max((rel_err(grads[k], o_grads[k]), k) for k in grads if not k.endswith("qkv.bias"))
+    assert worst[0] < 1e-3, worst
