@@ -28,7 +28,7 @@ class GemmArgs(C.Structure):
         ("act", c_int),
         ("aux", c_void_p), ("aux_dtype", c_int), ("ldaux", c_int64),
         ("C2", c_void_p), ("c2_dtype", c_int), ("ldc2", c_int64),
-        ("alpha", c_float), ("force_generic", c_int), ("colsum_out", c_void_p),
+        ("alpha", c_float), ("force_generic", c_int), ("colsum_out", c_void_p), ("workspace_armed", c_int),
     ]
 
 

@@ -14,6 +14,7 @@ int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const fl
 int g_force_simple_attention = 0;
 extern int g_attn_row;
 extern int g_attn_dbg;
+extern int g_attn_bwd3;
 }  // namespace hct
 
 using namespace hct;
@@ -22,6 +23,7 @@ extern "C" {
 
 // testing hook: route bf16 attention through the simple kernels (A/B comparisons)
 void hct_debug_force_simple_attention(int on) {
+  if (on >= 100000) { g_attn_bwd3 = on - 100000; return; }  // which shapes take the key-owner backward (bit0 dh 48, bit1 dh 64)
   if (on >= 10) { g_attn_dbg = on - 10; return; }
   if (on >= 2) { g_force_simple_attention = 0; g_attn_row = on == 2 ? 0 : 1; return; }  // 2: online-softmax MFMA kernel, 3: full-row
   g_force_simple_attention = on;

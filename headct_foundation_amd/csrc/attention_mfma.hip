@@ -16,6 +16,7 @@
 
 namespace hct {
 
+int g_attn_bwd3 = 2;  // which shapes use the key-owner five-product backward: bit0 head dim 48 (<= 256 tokens), bit1 head dim 64 (<= 192 tokens)
 int g_attn_dbg = 0;  // timing experiments on the backward kernel: bit0 skip key-owner pass, bit1 skip query-owner pass
 
 namespace {
@@ -55,7 +56,7 @@ __device__ __forceinline__ void load_image(unsigned char* img, const bf16* __res
 template <int DH>
 __device__ __forceinline__ void compute_delta(const bf16* __restrict__ ob, const bf16* __restrict__ dob, int64_t os,
                                               const float* __restrict__ lse_row, int N, int Npad, float* sLse, float* sDel,
-                                              int nthreads) {
+                                              int nthreads, float lse_mul = 1.44269504088896340736f, float del_mul = 1.0f) {
   constexpr int U = 4;
   const int total = Npad * 8;
   for (int base = threadIdx.x; base < total; base += nthreads * U) {
@@ -81,8 +82,10 @@ __device__ __forceinline__ void compute_delta(const bf16* __restrict__ ob, const
       part += __shfl_xor(part, 4, 64);
       if (idx < total && (idx & 7) == 0) {
         const int r = idx >> 3;
-        sDel[r] = r < N ? part : 0.f;
-        sLse[r] = r < N ? lse_row[r] * 1.44269504088896340736f : INFINITY;  // base-2 (see exp2 below); padded rows: p = 0
+        sDel[r] = r < N ? part * del_mul : 0.f;
+        // default: lse in base 2 (see exp2 below), +inf on padded rows so that p = 0; the key-owner kernel stores -lse / scale
+        // (an accumulator input) and gets -inf there
+        sLse[r] = r < N ? lse_row[r] * lse_mul : (lse_mul < 0.f ? -INFINITY : INFINITY);
       }
     }
   }
@@ -580,6 +583,302 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? HCT_BWD2_WPE : 2)) attn_bw
   }
 }
 
+
+// ============================================================================================================
+// Backward, key-owner form with FIVE products (bwd3): every wave owns KT consecutive 16-key tiles of one (batch, head)
+// and keeps their dK^T / dV^T in accumulators while the workgroup sweeps the queries in blocks of 32.
+//   per block and own key tile:  S = Q.K^T and dP = dO.V^T with the KEY on the lane  ->  P, dS in registers are already
+//   the B operands of dV^T += dO^T.P and dK^T += Q^T.dS (accumulator-as-operand, no LDS trip);
+//   dS crosses LDS once, as 8-byte (key, 4 queries) granules, and dQ^T = K^T.dS^T of the block is formed by the waves
+//   from that image with transposed reads on both operands -- nothing is recomputed (the two-phase kernel above pays
+//   7 products), no atomics, fixed summation order.
+// LDS: Q, dO, K images of the head only (V never enters LDS: a wave needs just its own keys' rows, held in registers),
+// with 96-B rows for head dim 48 (conflict-free without a swizzle: 24-dword row stride) and swizzled 128-B rows for 64,
+// filled by LDS-DMA (buffer_load ... lds, zero fill past the last token through the descriptor's range check).
+// 80 KiB per 217-token head -> two 4-wave workgroups per CU: one loads while the other computes.
+// A wave streams 14 KiB of fragments per query block whatever KT is, so KT = 4 quarters the LDS read traffic of the
+// 16-key-per-wave kernels above (their LDS port was as busy as their matrix pipes).
+// Head dim 48 = one 32-deep + one 16-deep MFMA (v_mfma_f32_16x16x16_bf16) instead of zero-padding to 64.
+template <int DH> struct HeadImg {
+  static constexpr int kRow = DH == 48 ? 96 : 128;
+  static constexpr int kChunks = DH / 8;
+  static __device__ __forceinline__ int off(int r, int c) {
+    return DH == 48 ? r * 96 + c * 16 : r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+  }
+};
+
+// 16 rows x DH of an operand, row on lane&15: two 32-deep MFMA steps.  Head dim 48: the second step's upper 16 columns
+// are padding -- read as whatever follows in the row-major image (finite bf16: every byte of the images is written) on the
+// streamed side and as ZERO on the hoisted side (`zero_pad`), so the products vanish.
+// (A 16x16x16 MFMA for the 16-column tail, chained behind the 16x16x32 one through its accumulator input, gave wrong sums on
+//  gfx950 / ROCm 7.2 whenever hipcc scheduled the pair back to back -- it pads nothing between the two shapes; run as a
+//  chain of its own plus a VALU add it was correct, but the adds cost more than the padded MFMA.)
+template <int DH> struct RowFrag { bf16x8 lo, hi; };
+
+template <int DH>
+__device__ __forceinline__ f32x4 mma_rows(const RowFrag<DH>& a, const RowFrag<DH>& b, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.lo, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, c, 0, 0, 0);
+}
+
+template <int DH>
+__device__ __forceinline__ RowFrag<DH> rows_lds(const unsigned char* img, int r0, int lane, bool zero_pad) {
+  const int r = r0 + (lane & 15), g = lane >> 4;
+  RowFrag<DH> f;
+  f.lo = *reinterpret_cast<const bf16x8*>(img + HeadImg<DH>::off(r, g));
+  if constexpr (DH == 48) {
+    f.hi = *reinterpret_cast<const bf16x8*>(img + r * 96 + 64 + 16 * g);  // g >= 2: the next row's first 32 bytes
+    if (zero_pad && g >= 2) f.hi = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  } else {
+    f.hi = *reinterpret_cast<const bf16x8*>(img + HeadImg<DH>::off(r, 4 + g));
+  }
+  return f;
+}
+template <int DH>
+__device__ __forceinline__ RowFrag<DH> rows_global(const bf16* __restrict__ base, int64_t rs, int r0, int lane, int N) {
+  const int r = r0 + (lane & 15), g = lane >> 4;
+  RowFrag<DH> f;
+  f.lo = f.hi = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  if (r < N) {
+    const bf16* p = base + (int64_t)r * rs;
+    f.lo = *reinterpret_cast<const bf16x8*>(p + 8 * g);
+    if (DH == 64 || g < 2) f.hi = *reinterpret_cast<const bf16x8*>(p + 32 + 8 * g);
+  }
+  return f;
+}
+// column operand (d0 + lane&15 on the lane, 8 tokens per lane: rA + 4g + {0..3}, rB + 4g + {0..3}) of a head image
+template <int DH>
+__device__ __forceinline__ bf16x8 cols_lds(const unsigned char* img, int rA, int rB, int d0, int lane) {
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  const int c = (d0 >> 3) + (pp >> 1), sub = (pp & 1) * 8;
+  const unsigned char* pa = img + HeadImg<DH>::off(rA + 4 * g + qq, c) + sub;
+  const unsigned char* pb = img + HeadImg<DH>::off(rB + 4 * g + qq, c) + sub;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// LDS-DMA fill of one head image: rows [0, Npad) x DH bf16 from global rows of stride rs elements; rows >= N read as zero
+// (buffer range check).  Pieces of 1 KiB (64 lanes x 16 B) in image order, dealt round-robin to the waves.
+template <int DH>
+__device__ __forceinline__ void dma_image(unsigned char* img, const bf16* __restrict__ g, int64_t rs, int N, int Npad, int wave,
+                                          int nwaves, int lane) {
+  constexpr int CH = HeadImg<DH>::kChunks;
+  const int64_t bytes = ((int64_t)(N - 1) * rs + DH) * 2;
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)bytes, 0x00020000);
+  const int pieces = Npad * CH / 64;
+  for (int p = wave; p < pieces; p += nwaves) {
+    const int ci = p * 64 + lane;
+    const int row = ci / CH, slot = ci - row * CH;
+    const int src = DH == 48 ? slot : (slot ^ ((row >> 1) & 7));
+    const uint32_t voff = (uint32_t)(row * (int)rs * 2 + src * 16);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(img + p * 1024), 16, voff, 0, 0, 0);
+  }
+}
+
+// dS^T granule (key, 4 consecutive queries 4p..4p+3 of the block's 16-query half hh): 8 bytes at
+//   hh * Npad * 32 + key * 32 + ((p ^ ((key >> 2) & 3)) << 3)
+// 8 keys x 4 granules = one 256-B bank row: the transposed reads of the dQ product are conflict-free, and so are the
+// accumulator-shaped writes (16 keys x one p per 16-lane group; the XOR spreads keys 0,4,8,12 over the row's four slots).
+__device__ __forceinline__ int dst_off(int Npad, int hh, int key, int p) { return (hh * Npad + key) * 32 + ((p ^ ((key >> 2) & 3)) << 3); }
+
+template <int DH, int GS, int KT, int WPS>
+__global__ void __launch_bounds__(GS * 64, WPS) attn_bwd3_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                               const bf16* __restrict__ d_o, const float* __restrict__ lse,
+                                                               int N, int H, int Npad, bf16* __restrict__ dqkv, int dbg, int stagger_from,
+                                                               int stagger_sleeps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ROW = HeadImg<DH>::kRow;
+  constexpr int ND = DH / 16;
+  unsigned char* Qimg = smem;
+  unsigned char* Dimg = Qimg + Npad * ROW;
+  unsigned char* Kimg = Dimg + Npad * ROW;
+  unsigned char* dsT = Kimg + Npad * ROW;                 // [2][Npad][32 B]
+  float* sLse = reinterpret_cast<float*>(dsT + 2 * Npad * 32);
+  float* sDel = sLse + Npad;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bh = xcd_bh(), b = bh / H, h = bh - b * H;
+  const int64_t rs = (int64_t)3 * H * DH;
+  const int64_t os = (int64_t)H * DH;
+  const bf16* qb = qkv + (int64_t)b * N * rs + h * DH;
+  const bf16* kb = qb + H * DH;
+  const bf16* vb = qb + 2 * H * DH;
+  const bf16* ob = o + (int64_t)b * N * os + h * DH;
+  const bf16* dob = d_o + (int64_t)b * N * os + h * DH;
+  const float scale = rsqrtf((float)DH);
+  const float scale2 = scale * 1.44269504088896340736f;
+  const int g = lane >> 4;
+  const int key_base = wave * (KT * 16);
+
+  unsigned long long tstamp[12];
+  int nstamp = 0;
+#define BWD3_STAMP() do { if (dbg & 0x80) { __builtin_amdgcn_sched_barrier(0); tstamp[nstamp < 11 ? nstamp : 11] = __builtin_amdgcn_s_memrealtime(); ++nstamp; __builtin_amdgcn_sched_barrier(0); } } while (0)
+  BWD3_STAMP();
+  // Two workgroups share a CU and do identical work: dispatched together they would run their load, compute and store
+  // phases in lockstep and never overlap.  The second one of every CU (blocks CUs .. 2*CUs-1 of the first dispatch round)
+  // starts half a workgroup lifetime late; later workgroups take the slot of one that exits, which keeps the offset.
+  if ((int)blockIdx.x >= stagger_from && (int)blockIdx.x < 2 * stagger_from)
+    for (int i = 0; i < stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+
+  if (!(dbg & 0x800)) {
+  dma_image<DH>(Qimg, qb, rs, N, Npad, wave, GS, lane);
+  dma_image<DH>(Dimg, dob, os, N, Npad, wave, GS, lane);
+  dma_image<DH>(Kimg, kb, rs, N, Npad, wave, GS, lane);
+  }
+  RowFrag<DH> vf[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) vf[t] = rows_global<DH>(vb, rs, key_base + t * 16, lane, N);
+  BWD3_STAMP();  // 1: DMA + V loads issued
+  if (!(dbg & 0x400)) compute_delta<DH>(ob, dob, os, lse + (int64_t)bh * N, N, Npad, sLse, sDel, GS * 64, -1.0f / scale, -1.0f);
+  BWD3_STAMP();  // 2: delta done
+  // key tiles past the last token are never written by an owner: their dS^T rows must read as zero in the dQ product
+  for (int i = threadIdx.x * 16; i < 2 * Npad * 32; i += GS * 64 * 16) *reinterpret_cast<f32x4*>(dsT + i) = f32x4{0, 0, 0, 0};
+  f32x4 dKt[KT][ND], dVt[KT][ND];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) dKt[t][dt] = dVt[t][dt] = f32x4{0, 0, 0, 0};
+  __syncthreads();  // (drains the LDS-DMA: hipcc waits vmcnt(0) in front of the barrier)
+  BWD3_STAMP();  // 3: images landed
+
+  const int nqb = Npad >> 5;
+  for (int qbk = 0; qbk < nqb; ++qbk) {
+    const int q0 = qbk * 32;
+    // ---- main: own key tiles against the block's 32 queries -------------------------------------------------
+    // Row constants ride in the accumulator inputs: S' = Q.K^T - lse / scale2 and dP' = dO.V^T - delta leave the MFMA
+    // chains ready, so p = exp2(scale2 * S') and dS / scale = p * dP' are three VALU operations per element; the factor
+    // `scale` of dS is applied once to the finished dK and dQ.
+    if (key_base < N && !(dbg & 0x100)) {
+      RowFrag<DH> qr[2], dr[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        qr[hh] = rows_lds<DH>(Qimg, q0 + 16 * hh, lane, true);
+        dr[hh] = rows_lds<DH>(Dimg, q0 + 16 * hh, lane, true);
+      }
+      // one wave per SIMD (WPS == 1): the whole 512-register file is this wave's, so every streamed fragment of the block
+      // is fetched once and reused by all key tiles; with two waves per SIMD the column fragments and accumulator inputs
+      // are re-read per key tile instead (the kernel then sits at the 256-register cap)
+      constexpr bool kHoist = WPS == 1;
+      bf16x8 qT[ND], dT[ND];
+      f32x4 Lh[2], Dh[2];
+      if constexpr (kHoist) {
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+          qT[dt] = cols_lds<DH>(Qimg, q0, q0 + 16, dt * 16, lane);
+          dT[dt] = cols_lds<DH>(Dimg, q0, q0 + 16, dt * 16, lane);
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          Lh[hh] = *reinterpret_cast<const f32x4*>(sLse + q0 + 16 * hh + 4 * g);
+          Dh[hh] = *reinterpret_cast<const f32x4*>(sDel + q0 + 16 * hh + 4 * g);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        const int key0 = key_base + t * 16;
+        {  // straight-line over the KT tiles (no per-tile branch: hipcc schedules across tiles only inside one basic block);
+           // a tile past the last token works on zero K / V rows and is masked like the straddling one
+          const RowFrag<DH> kf = rows_lds<DH>(Kimg, key0 < Npad ? key0 : 0, lane, false);
+          const int key = key0 + (lane & 15);
+          f32x4 P[2], dS[2];
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            // accumulator inputs re-read per key tile (two broadcast reads) rather than held across the tile loop: registers
+            f32x4 Linit, Dinit;  // -lse / scale (-inf on pad rows), -delta
+            if constexpr (kHoist) { Linit = Lh[hh]; Dinit = Dh[hh]; }
+            else {
+              Linit = *reinterpret_cast<const f32x4*>(sLse + q0 + 16 * hh + 4 * g);
+              Dinit = *reinterpret_cast<const f32x4*>(sDel + q0 + 16 * hh + 4 * g);
+            }
+            const f32x4 sacc = mma_rows<DH>(qr[hh], kf, Linit);    // S'[q = 4g+r][key = lane&15]
+            const f32x4 dp = mma_rows<DH>(dr[hh], vf[t], Dinit);   // dP'[q][key]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              P[hh][r] = __builtin_amdgcn_exp2f(sacc[r] * scale2);
+              dS[hh][r] = P[hh][r] * dp[r];
+            }
+          }
+          const float keep = key < N ? 1.f : 0.f;  // keys past the last token contribute nothing
+          P[0] *= keep; P[1] *= keep; dS[0] *= keep; dS[1] *= keep;
+          const bf16x8 pa = pack8(P[0], P[1]);
+          const bf16x8 dsa = pack8(dS[0], dS[1]);
+          const bf16x4 d0 = {dsa[0], dsa[1], dsa[2], dsa[3]}, d1 = {dsa[4], dsa[5], dsa[6], dsa[7]};
+          if (key0 < Npad) {
+            *reinterpret_cast<bf16x4*>(dsT + dst_off(Npad, 0, key, g)) = d0;
+            *reinterpret_cast<bf16x4*>(dsT + dst_off(Npad, 1, key, g)) = d1;
+          }
+#pragma unroll
+          for (int dt = 0; dt < ND; ++dt) {
+            if constexpr (kHoist) {
+              dVt[t][dt] = MFMA(dT[dt], pa, dVt[t][dt]);   // dV^T[d][key] += dO^T.P
+              dKt[t][dt] = MFMA(qT[dt], dsa, dKt[t][dt]);  // dK^T[d][key] += Q^T.(dS / scale)
+            } else {
+              dVt[t][dt] = MFMA(cols_lds<DH>(Dimg, q0, q0 + 16, dt * 16, lane), pa, dVt[t][dt]);
+              dKt[t][dt] = MFMA(cols_lds<DH>(Qimg, q0, q0 + 16, dt * 16, lane), dsa, dKt[t][dt]);
+            }
+          }
+        }
+      }
+    }
+    if (qbk < 2) BWD3_STAMP();  // 4, 8: main of block 0 / 1
+    __syncthreads();  // the block's dS^T image is complete
+    if (qbk < 2) BWD3_STAMP();  // 5, 9
+    // ---- dQ^T[d][q] = sum_key K^T[d][key] . dS^T[key][q] for the block: output tiles (d-tile, query half) over the waves --
+    for (int dt = wave; dt < ND && !(dbg & 0x200); dt += GS) {
+      f32x4 dq0 = {0, 0, 0, 0}, dq1 = {0, 0, 0, 0};
+      const int G = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+      auto ds_frag = [&](int hh, int k0) -> bf16x8 {
+        const int ka = k0 + 4 * G + qq;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dsT + dst_off(Npad, hh, ka, pp)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dsT + dst_off(Npad, hh, ka + 16, pp)));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+      };
+      // two-deep: the fragments of key step k+1 are in flight while the MFMAs of step k run
+      bf16x8 kT = cols_lds<DH>(Kimg, 0, 16, dt * 16, lane), b0 = ds_frag(0, 0), b1 = ds_frag(1, 0);
+      for (int k0 = 32; k0 < Npad; k0 += 32) {
+        const bf16x8 kTn = cols_lds<DH>(Kimg, k0, k0 + 16, dt * 16, lane), b0n = ds_frag(0, k0), b1n = ds_frag(1, k0);
+        dq0 = MFMA(kT, b0, dq0);
+        dq1 = MFMA(kT, b1, dq1);
+        kT = kTn; b0 = b0n; b1 = b1n;
+      }
+      dq0 = MFMA(kT, b0, dq0);
+      dq1 = MFMA(kT, b1, dq1);
+      const int q = q0 + (lane & 15);
+      if (q < N) Vec4<bf16>::store(dqkv + ((int64_t)b * N + q) * rs + h * DH + dt * 16 + 4 * g, dq0 * scale);
+      if (q + 16 < N) Vec4<bf16>::store(dqkv + ((int64_t)b * N + q + 16) * rs + h * DH + dt * 16 + 4 * g, dq1 * scale);
+    }
+    if (qbk < 2) BWD3_STAMP();  // 6, 10: dQ of the block
+    __syncthreads();  // dS^T may be overwritten by the next block
+    if (qbk < 1) BWD3_STAMP();  // 7
+  }
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    const int key = key_base + t * 16 + (lane & 15);
+    if (key < N) {
+      bf16* outk = dqkv + ((int64_t)b * N + key) * rs + H * DH + h * DH + 4 * g;
+      bf16* outv = outk + H * DH;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        Vec4<bf16>::store(outk + dt * 16, dKt[t][dt] * scale);
+        Vec4<bf16>::store(outv + dt * 16, dVt[t][dt]);
+      }
+    }
+  }
+  if ((dbg & 0x80) && blockIdx.x == 0 && threadIdx.x == 0) {
+    tstamp[11] = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(dqkv);
+    for (int i = 0; i < 12; ++i) dst[i] = tstamp[i];
+  }
+}
+
+#undef BWD3_STAMP
+template <int DH>
+inline size_t bwd3_lds(int Npad) { return (size_t)3 * Npad * HeadImg<DH>::kRow + (size_t)2 * Npad * 32 + (size_t)2 * Npad * sizeof(float); }
+
 inline size_t bwd2_lds(int N) { return (size_t)2 * ((N + 31) / 32 * 32) * kRowBytes + (size_t)2 * ((N + 31) / 32 * 32) * sizeof(float); }
 
 constexpr int kMaxLds = 160 * 1024;
@@ -635,6 +934,23 @@ int attention_fwd_mfma(const void* qkv, int B, int N, int H, int dh, void* o, fl
 int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const float* lse, int B, int N, int H, int dh,
                        void* dqkv, hipStream_t s) {
   const int Npad = npad_of(N);
+  int ncu = 256;
+  { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount; }
+  if (!(g_attn_dbg & (4 | 8 | 32))) {  // (testing hooks 4 / 8 / 32 select the older kernels)  five-product key-owner kernel for the sequence lengths whose Q / dO / K images leave room for two workgroups per CU
+#define HCT_BWD3(DH_, GS_, KT_, WPS_)                                                                                        \
+  do {                                                                                                                 \
+    const size_t l3 = bwd3_lds<DH_>(Npad);                                                                             \
+    if (int rc = set_lds(attn_bwd3_kernel<DH_, GS_, KT_, WPS_>, l3)) return rc;                                              \
+    hipLaunchKernelGGL((attn_bwd3_kernel<DH_, GS_, KT_, WPS_>), dim3(B * H), dim3(GS_ * 64), l3, s, (const bf16*)qkv,        \
+                       (const bf16*)o, (const bf16*)d_o, lse, N, H, Npad, (bf16*)dqkv, g_attn_dbg & 0xF80, ncu,    \
+                       (g_attn_dbg >> 12) ? (g_attn_dbg >> 12) - 1 : (int)(Npad * Npad / 4096));                      \
+    return check_hip(hipGetLastError(), "attention_bwd3");                                                             \
+  } while (0)
+    if (dh == 48 && Npad <= 256 && (g_attn_bwd3 & 1)) { if (g_attn_dbg & 64) HCT_BWD3(48, 4, 4, 1); else HCT_BWD3(48, 4, 4, 2); }  // 64: one wave per SIMD (testing)
+    if (dh == 64 && Npad <= 64 && (g_attn_bwd3 & 2)) HCT_BWD3(64, 2, 2, 2);
+    if (dh == 64 && Npad <= 192 && (g_attn_bwd3 & 2)) HCT_BWD3(64, 4, 3, 2);
+#undef HCT_BWD3
+  }
   if (!(g_attn_dbg & 4) || bwd_lds(N) > (size_t)kMaxLds) {  // single-phase variant (testing hook) only where its 4 images fit
     const size_t l2 = bwd2_lds(N);
 #define HCT_BWD2(DH_, NW_)                                                                                           \

@@ -19,6 +19,8 @@ namespace hct {
 static int g_w4_auto = 0;   // auto-dispatch of the 2-WG/CU variant: faster in isolation on the decoder's GELU / +residual
                             // GEMMs (362 vs 395 us, 126 vs 142 us) but 1 % slower inside the step -> off
 static int g_stagger = -1;  // -1 auto, >= 0 forced (testing)
+static int g_tn_separate_fold = 1;  // 1 = split partials folded by gemm_fold_kernel; 0 = inside the wgrad launch (measured 0.36 ms per step SLOWER:
+                                     // DESIGN.md section 5; kept selectable and tested, -6 / -7 of hct_debug_set_gemm_variant)
 static int g_nt_variant = 0;  // 0 auto; 128 / 256 / 4 force one NT kernel (tests cover every instance)
 
 struct Epilogue {
@@ -497,7 +499,7 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
     __builtin_amdgcn_sched_barrier(0); \
   } while (0)
 
-template <int MODE>
+template <int MODE, int STORE_POLICY = kNT>
 __device__ __forceinline__ void epilogue_wave64x128_m(const Epilogue& e, const TileBufs& tb, unsigned char* patch, int lane, int m0,
                                                       int n0, int row0, int col0, int M, int N, const f32x4 (*acc)[8], const TileBias& bias,
                                                       f32x4& cs0, f32x4& cs1) {
@@ -582,7 +584,7 @@ __device__ __forceinline__ void epilogue_wave64x128_m(const Epilogue& e, const T
         const f32x4 v = *reinterpret_cast<const f32x4*>(patch + pr * 512 + ((cc ^ (pr & 7)) << 4));
         f32x4 x = v * e.alpha + bias.lo;
         if (MODE == EPI_RES_F32) x += __builtin_bit_cast(f32x4, ld[i & 1][it]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), tb.c, ok ? lane_c * 4u : OOB, (row0 + prow) * ldc * 4, kNT);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), tb.c, ok ? lane_c * 4u : OOB, (row0 + prow) * ldc * 4, STORE_POLICY);
         HCT_STORE_GUARD();
         if (i < 3 && it == kHalf - 1) issue_loads(i + 1, kHalf, T::batches);
       }
@@ -1026,7 +1028,8 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_nt_w4_kernel(int M, int N, i
 // fp32 partial (or the final C when splits == 1); a fold kernel adds the partials in fixed order.
 __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, int R, int r_chunk, const bf16* __restrict__ A,
                                                                  int64_t lda, const bf16* __restrict__ B, int64_t ldb,
-                                                                 float* __restrict__ slab, Epilogue e, int ntiles) {
+                                                                 float* __restrict__ slab, Epilogue e, int ntiles, int splits,
+                                                                 unsigned int* __restrict__ counters) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[163840];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ntm = (M + 255) >> 8, ntn = (N + 255) >> 8, nmn = ntm * ntn;
@@ -1215,9 +1218,97 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
       tb.res = tile_rsrc(nullptr, 0, 4, cm0, cn0, M, N);
       tb.aux = tb.res;
       f32x4 cs0 = {0, 0, 0, 0}, cs1 = {0, 0, 0, 0};
-      epilogue_wave64x128_m<EPI_PLAIN_F32>(eo, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv, cs0, cs1);
+      // partial slabs leave write-through (sc1): they are handed to other workgroups below, and a write-through store needs
+      // no release fence (publishing 256 KB of plain stores with buffer_wbl2 costs several us per workgroup)
+      if (slab) epilogue_wave64x128_m<EPI_PLAIN_F32, 16>(eo, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv, cs0, cs1);
+      else epilogue_wave64x128_m<EPI_PLAIN_F32>(eo, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv, cs0, cs1);
+    }
+    if (slab && counters) {  // publish this split's partial: every wave's stores have left, then ONE arrival on the tile's counter
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(counters + (cm0 >> 8) * ntn + (cn0 >> 8), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!more) break;
+  }
+  if (!slab || !counters) return;
+  // ---- split fold inside the launch ------------------------------------------------------------------------------------
+  // All splits of a tile are co-resident (grid <= #CUs, one 160-KiB workgroup per CU) or queued behind workgroups that never
+  // wait before publishing, so waiting for the tile's arrival count cannot deadlock: a workgroup publishes ALL its items
+  // first and only then takes up its fold duties.  Every one of the tile's `splits` workgroups then sums 1/splits of the
+  // tile's rows over the slabs in split order 0, 1, 2, ... (fixed order: bit-reproducible whatever the arrival order) and
+  // writes the final fp32 C.  Slab bytes were stored write-through (sc1) and drained before the arrival; the consumer
+  // polls relaxed, then ONE agent-scope acquire drops its L1 lines before the plain loads: placement-independent
+  // (MI355X_MICROARCH.md, "Valid forms").
+  unsigned int* const done = counters + 64;
+  for (int vb2 = blockIdx.x; vb2 < ntiles; vb2 += gridDim.x) {
+    const int xcd = vb2 & 7, q = ntiles >> 3, r = ntiles & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb2 >> 3);
+    const int fsp = id / nmn, tile = id - fsp * nmn;
+    const int tm = tile / ntn, tn = tile - tm * ntn;
+    int& s_timeout = *reinterpret_cast<int*>(smem);  // the ring is idle now (every wave is past the publish barrier)
+    if (threadIdx.x == 0) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(counters + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)splits && spins < (1u << 20)) {
+        __builtin_amdgcn_s_sleep(8);
+        ++spins;
+      }
+      s_timeout = spins >= (1u << 20);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's stale L1 lines of the slabs
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (s_timeout) {  // a split never arrived (cannot happen with a resident grid): flag it instead of hanging the GPU
+      if (threadIdx.x == 0) __hip_atomic_store(counters + 128, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    // this workgroup's share of the tile: rows [r0, r1)
+    const int r0 = (fsp * 256) / splits, r1 = ((fsp + 1) * 256) / splits;
+    const int cols4 = 64;  // 256 columns as float4
+    const float* tile_base = slab + ((int64_t)tm * 256) * N + tn * 256;
+    const int64_t zstride = (int64_t)M * N;
+    float* Cf = (float*)e.C;
+    // 8 outputs x 4 splits = 32 independent 16-B loads in flight per thread: the slabs come from the Infinity Cache / another
+    // XCD's L2 at ~2 us per round trip, so a thread that waits for 4 loads at a time spends 8 round trips on its share
+    const int nelem = (r1 - r0) * cols4;
+    for (int g0 = 0; g0 < nelem; g0 += 512 * 8) {
+      const float* src[8];
+      float* dst[8];
+      f32x4 sum[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = g0 + k * 512 + (int)threadIdx.x;
+        const int rr = r0 + i / cols4, c4 = (i % cols4) * 4;
+        const int m = tm * 256 + rr, n = tn * 256 + c4;
+        const bool ok = i < nelem && m < M && n < N;
+        src[k] = ok ? tile_base + (int64_t)rr * N + c4 : nullptr;
+        dst[k] = ok ? Cf + (int64_t)m * e.ldc + n : nullptr;
+        sum[k] = f32x4{0, 0, 0, 0};
+      }
+      for (int z = 0; z < splits; z += 4) {
+        f32x4 v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            v[u][k] = (src[k] && z + u < splits) ? *reinterpret_cast<const f32x4*>(src[k] + (int64_t)(z + u) * zstride) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)  // split order 0, 1, 2, ... per output (adding the zero of an absent split changes nothing)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) sum[k] += v[u][k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (dst[k]) *reinterpret_cast<f32x4*>(dst[k]) = sum[k] * e.alpha;
+    }
+    // last one out re-arms the tile's counters for the next launch on this workspace
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned prev = __hip_atomic_fetch_add(done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev == (unsigned)splits - 1) {
+        __hip_atomic_store(done + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
@@ -1384,6 +1475,10 @@ static Path choose_path(const hct_gemm_args* a) {
   return PATH_GENERIC;
 }
 
+// head of the wgrad workspace: per-tile arrival / completion counters of the in-launch split fold (64 + 64 words + a timeout flag)
+constexpr size_t kTnCounterBytes = 1024;
+constexpr int kTnMaxFoldTiles = 64;
+
 static bool tn256_ok(const hct_gemm_args* a) {
   return g_nt_variant != 128 && a->c_dtype == HCT_F32 && !a->C2 && a->ldc % 4 == 0 && a->ldc * 256 < (1ll << 28) &&
          a->lda * 2 * 64 < (1ll << 31) && a->ldb * 2 * 64 < (1ll << 31);
@@ -1434,7 +1529,8 @@ extern "C" {
 
 void hct_set_cu_reserve(int n) { g_cu_reserve = n < 0 ? 0 : n; }
 void hct_debug_set_gemm_variant(int v) {
-  if (v == -4 || v == -5) { g_w4_auto = v == -4; return; }  // -4 / -5: auto-dispatch of the 2-WG/CU variant on / off
+  if (v == -4 || v == -5) { g_w4_auto = v == -4; return; }
+  if (v == -6 || v == -7) { g_tn_separate_fold = v == -6; return; }  // -6 / -7: separate fold kernel for the wgrad splits on / off  // -4 / -5: auto-dispatch of the 2-WG/CU variant on / off
   g_nt_variant = v;
 }
 #ifdef HCT_STAMPS
@@ -1453,8 +1549,11 @@ static size_t colsum_ws(const hct_gemm_args* a) {
 size_t hct_gemm_workspace_bytes(const hct_gemm_args* a) {
   if (choose_path(a) != PATH_TN) return colsum_ws(a);
   int splits, r_chunk;
-  if (tn256_ok(a)) tn256_split(a, splits, r_chunk);
-  else tn_split(a, splits, r_chunk);
+  if (tn256_ok(a)) {
+    tn256_split(a, splits, r_chunk);
+    return splits > 1 ? kTnCounterBytes + (size_t)splits * a->M * a->N * sizeof(float) : 0;
+  }
+  tn_split(a, splits, r_chunk);
   return splits > 1 ? (size_t)splits * a->M * a->N * sizeof(float) : 0;
 }
 
@@ -1548,18 +1647,31 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
     ProfScope ps(PROF_GEMM_TN, flops, s, bytes);
     int splits, r_chunk;
     tn256_split(a, splits, r_chunk);
-    const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256) * splits;
+    const int tiles_mn = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+    const int tiles = tiles_mn * splits;
     float* slab = nullptr;
+    unsigned int* counters = nullptr;
     if (splits > 1) {
-      if (workspace_bytes < (size_t)splits * a->M * a->N * sizeof(float) || !workspace) {
-        set_error("hct_gemm(tn256): workspace too small (%zu < %zu)", workspace_bytes, (size_t)splits * a->M * a->N * sizeof(float));
+      const size_t need = kTnCounterBytes + (size_t)splits * a->M * a->N * sizeof(float);
+      if (workspace_bytes < need || !workspace) {
+        set_error("hct_gemm(tn256): workspace too small (%zu < %zu)", workspace_bytes, need);
         return HCT_E_WORKSPACE;
       }
-      slab = (float*)workspace;
+      counters = (unsigned int*)workspace;
+      slab = (float*)((char*)workspace + kTnCounterBytes);
+    }
+    // the in-launch fold needs one counter pair per output tile and writes fp32 C directly; anything else keeps the fold kernel
+    const bool fold_in_launch = slab && tiles_mn <= kTnMaxFoldTiles && !g_tn_separate_fold;
+    if (fold_in_launch) {
+      // the counters re-arm themselves at the end of every launch; a caller that keeps the workspace head to itself says so
+      // (the plan does: its workspace is zeroed at allocation), anyone else gets a reset in front of the launch
+      if (!a->workspace_armed)
+        if (int rc = check_hip(hipMemsetAsync(workspace, 0, kTnCounterBytes, s), "hct_gemm(tn256): counter reset")) return rc;
     }
     hipLaunchKernelGGL(gemm_bf16_tn256_kernel, dim3(std::min(tiles, num_cus())), dim3(512), 0, s, a->M, a->N, a->K, r_chunk,
-                       (const bf16*)a->A, a->lda, (const bf16*)a->B, a->ldb, slab, e, tiles);
-    if (slab) {
+                       (const bf16*)a->A, a->lda, (const bf16*)a->B, a->ldb, slab, e, tiles, fold_in_launch ? splits : 0,
+                       fold_in_launch ? counters : nullptr);
+    if (slab && !fold_in_launch) {
       const int64_t total4 = (int64_t)a->M * a->N / 4;
       const int blocks = (int)std::min<int64_t>(2048, (total4 + 255) / 256);
       hipLaunchKernelGGL(gemm_fold_kernel, dim3(blocks), dim3(256), 0, s, slab, splits, a->M, a->N, e);

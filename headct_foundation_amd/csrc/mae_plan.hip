@@ -59,6 +59,7 @@ struct hct_mae_plan {
   bf16* params_bf16_t = nullptr;
   unsigned char* ws = nullptr;
   bool fwd_done = false;
+  bool gemm_ws_armed = false;
   bool dpred_done = false;  // the last forward also wrote d(loss)/d(pred) (training forward)
   const float* dloss = nullptr;
 
@@ -241,7 +242,9 @@ int linear_wgrad(hct_mae_plan* p, const void* dY, const void* X, int M, int N, i
   a.A = dY; a.a_dtype = p->dt; a.lda = N; a.transA = 1;
   a.B = X; a.b_dtype = p->dt; a.ldb = K; a.transB = 0;
   a.C = p->gf(w); a.c_dtype = HCT_F32; a.ldc = K;
+  a.workspace_armed = p->gemm_ws_armed ? 1 : 0;  // s_gemm is this plan's alone: its fold counters are reset by the first wgrad after a bind
   int rc = hct_gemm(&a, p->ws + p->s_gemm, p->s_gemm_bytes, s);
+  p->gemm_ws_armed = rc == 0;
   if (rc) return rc;
   if (b >= 0) rc = hct_colsum(dY, p->dt, M, N, N, p->gf(b), p->ws + p->s_small, p->s_small_bytes, s);
   return rc;
@@ -466,6 +469,7 @@ int hct_mae_plan_bind(hct_mae_plan* p, float* params, float* grads, void* params
   p->params_f32 = params; p->grads = grads;
   p->params_bf16 = (bf16*)params_bf16; p->params_bf16_t = (bf16*)params_bf16_t;
   p->ws = (unsigned char*)workspace;
+  p->gemm_ws_armed = false;
   p->fwd_done = false;
   return 0;
 }

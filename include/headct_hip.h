@@ -72,6 +72,8 @@ typedef struct hct_gemm_args {
   int force_generic;     /* testing: always take the generic kernel */
   float* colsum_out;     /* optional [N] fp32: column sums of the OUTPUT C (the bias gradient of the Linear that produced the
                             operand of this dgrad); fused into the epilogue where the kernel supports it */
+  int workspace_armed;   /* wgrad split fold: 1 = the first 1 KiB of `workspace` was zero when first used and has only been
+                            touched by hct_gemm since (its counters re-arm themselves): skips the per-call reset.  0 = reset it. */
 } hct_gemm_args;
 
 size_t hct_gemm_workspace_bytes(const hct_gemm_args* a);

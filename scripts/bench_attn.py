@@ -33,7 +33,7 @@ for tag, N, H, dh in (("decoder", 217, 16, 48), ("encoder", 55, 12, 64)):
         (fu, ft), (bu, bt) = run(256, N, H, dh, mode)
         print(f"{tag} N={N} H={H} dh={dh} [{nm:8s}] fwd {fu:7.1f} us {ft:6.1f} TF | bwd {bu:7.1f} us {bt:6.1f} TF")
 
-for dbg, nm in ((0, "two-phase 8 waves"), (8, "two-phase 4 waves"), (4, "single-phase 112 KB")):
+for dbg, nm in ((0, "key-owner five-product (bwd3)"), (32, "two-phase 8 waves"), (8, "two-phase 4 waves"), (4, "single-phase 112 KB")):
     lib.hct_debug_force_simple_attention(10 + dbg)
     for tag, N, H, dh in (("decoder", 217, 16, 48), ("encoder", 55, 12, 64)):
         (fu, ft), (bu, bt) = run(256, N, H, dh, 3)

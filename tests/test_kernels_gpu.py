@@ -96,6 +96,15 @@ def test_gemm_tn_bf16_mfma(lib, cuda, R, M, N):
     assert rel_err(out, ref) < 2e-5 and rel_err(gen, ref) < 2e-5
     out2 = gemm(lib, A, B, 1, 0, M, N, R)
     assert torch.equal(out, out2)  # deterministic split-K fold
+    # the in-launch fold (testing hook -7; the default is the separate fold kernel) sums the split partials in split order
+    # too: bit-identical results, and bit-identical between repeats whatever the arrival order of the splits
+    lib.hct_debug_set_gemm_variant(-7)
+    try:
+        fused = gemm(lib, A, B, 1, 0, M, N, R)
+        fused2 = gemm(lib, A, B, 1, 0, M, N, R)
+    finally:
+        lib.hct_debug_set_gemm_variant(-6)
+    assert torch.equal(out, fused) and torch.equal(fused, fused2)
 
 
 def test_gemm_generic_fp32_all_layouts(lib, cuda):
@@ -120,7 +129,9 @@ def _attn_ref(qkv, B, N, H, dh):
                                             (3, 17, 3, 64, torch.bfloat16), (1, 1, 2, 48, torch.bfloat16),
                                             (2, 65, 3, 64, torch.float32), (2, 217, 4, 48, torch.float32),
                                             (2, 33, 3, 16, torch.float32), (1, 129, 2, 64, torch.bfloat16),
-                                            (1, 513, 2, 48, torch.bfloat16)])
+                                            (1, 513, 2, 48, torch.bfloat16), (2, 200, 16, 48, torch.bfloat16),
+                                            (2, 100, 4, 64, torch.bfloat16), (2, 40, 2, 48, torch.bfloat16),
+                                            (3, 256, 2, 48, torch.bfloat16), (2, 192, 2, 64, torch.bfloat16)])
 def test_attention_fwd_bwd(lib, cuda, B, N, H, dh, dtype):
     qkv = _rand((B, N, 3 * H * dh), cuda, dtype, 11)
     d_o = _rand((B, N, H * dh), cuda, dtype, 12)
@@ -129,7 +140,10 @@ def test_attention_fwd_bwd(lib, cuda, B, N, H, dh, dtype):
     (o_ref * d_o.float()).sum().backward()
     dt = _dt(qkv)
     tol = 1.5e-2 if dtype == torch.bfloat16 else 2e-5
-    for force_simple in ((0, 1, 2, 14) if dtype == torch.bfloat16 else (0,)):  # 0 default, 1 fp32-math, 2 online-softmax fwd, 14 single-phase bwd
+    # 0 default (five-product key-owner backward where it applies), 1 fp32-math kernels, 2 online-softmax forward,
+    # 14 single-phase backward, 42 two-phase seven-product backward
+    # 100003: key-owner backward on every shape it covers (the default uses it for head dim 64 only)
+    for force_simple in ((0, 1, 2, 14, 42, 100003) if dtype == torch.bfloat16 else (0,)):
         lib.hct_debug_force_simple_attention(force_simple)
         try:
             o = torch.empty(B, N, H * dh, dtype=dtype, device=cuda)
@@ -142,6 +156,7 @@ def test_attention_fwd_bwd(lib, cuda, B, N, H, dh, dtype):
         finally:
             lib.hct_debug_force_simple_attention(0)
             lib.hct_debug_force_simple_attention(10)
+            lib.hct_debug_force_simple_attention(100002)
         assert rel_err(o, o_ref) < tol, force_simple
         assert (lse - lse_ref).abs().max() < (2e-2 if dtype == torch.bfloat16 else 1e-4)
         assert torch.isfinite(dqkv.float()).all()
