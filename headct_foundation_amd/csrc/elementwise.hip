@@ -638,6 +638,30 @@ __global__ void vit_assemble_fwd_kernel(const T* __restrict__ tok, const float* 
 }
 }  // namespace hct
 
+namespace hct {
+// HU windows (transforms.py:119-133 via MONAI ScaleIntensityRange, b_min 0, b_max 1, clip): W output channels per volume,
+//   out[b, w, v] = clip((hu[b, v] - a_min[w]) / (a_max[w] - a_min[w]), 0, 1)
+// fp32 subtract, IEEE divide, clip -- the operation order of the numpy / torch expression, so the fp32 result is the same
+// bit pattern; one pass over the HU volume feeds all W windows.  TOut = float or IEEE half (the persistent cache's type).
+template <typename TIn, typename TOut>
+__global__ void __launch_bounds__(256) hu_window_kernel(const TIn* __restrict__ hu, TOut* __restrict__ out, int W, int64_t vox4,
+                                                         const float* __restrict__ a_min, const float* __restrict__ a_max) {
+  const int b = blockIdx.y;
+  const TIn* src = hu + (int64_t)b * vox4 * 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < vox4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 x = Vec4<TIn>::load(src + i * 4);
+    for (int w = 0; w < W; ++w) {
+      const float lo = a_min[w], range = a_max[w] - a_min[w];
+      f32x4 y;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y[q] = fminf(fmaxf((x[q] - lo) / range, 0.0f), 1.0f);
+      Vec4<TOut>::store(out + (((int64_t)b * W + w) * vox4 + i) * 4, y);
+    }
+  }
+}
+}  // namespace hct
+
+
 // input transforms (transforms.py:193-228): cast + per-sample axis flips + intensity shift; one thread per 4 voxels of the
 // innermost axis (a flipped innermost axis is read as a reversed group of 4)
 namespace hct {
@@ -988,6 +1012,24 @@ int hct_pos_embed_interp3d(const float* src, int g_src, float* dst, int g_dst, i
   hipLaunchKernelGGL(hct::pos_embed_interp3d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, g_src, dst,
                      g_dst, D, extra);
   HCT_CHECK_LAUNCH("hct_pos_embed_interp3d");
+  return 0;
+}
+
+int hct_hu_window(const void* hu, int in_dtype, void* out, int out_dtype, int B, int64_t voxels, int n_windows, const float* a_min,
+                  const float* a_max, void* stream) {
+  HCT_REQUIRE(hu && out && a_min && a_max && B > 0 && voxels > 0 && voxels % 4 == 0 && n_windows > 0 && n_windows <= 8,
+              "hct_hu_window: bad arguments (voxels per volume must be a multiple of 4, 1..8 windows)");
+  HCT_REQUIRE((in_dtype == HCT_F32 || in_dtype == HCT_F16) && (out_dtype == HCT_F32 || out_dtype == HCT_F16), "hct_hu_window: dtypes are fp32 or fp16");
+  const int64_t vox4 = voxels / 4;
+  const dim3 grid((unsigned)std::min<int64_t>(1024, (vox4 + 255) / 256), (unsigned)B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define HCT_HUW(TI, TO) hipLaunchKernelGGL((hct::hu_window_kernel<TI, TO>), grid, block, 0, s, (const TI*)hu, (TO*)out, n_windows, vox4, a_min, a_max)
+  if (in_dtype == HCT_F32 && out_dtype == HCT_F32) HCT_HUW(float, float);
+  else if (in_dtype == HCT_F32) HCT_HUW(float, hct::f16);
+  else if (out_dtype == HCT_F32) HCT_HUW(hct::f16, float);
+  else HCT_HUW(hct::f16, hct::f16);
+#undef HCT_HUW
+  HCT_CHECK_LAUNCH("hct_hu_window");
   return 0;
 }
 

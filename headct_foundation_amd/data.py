@@ -43,6 +43,34 @@ class DeviceAugment:
         return out
 
 
+# (centre, width) of the reference's three-channel input (transforms.py:130) and its one-channel window 40 +- 150 (:121-122)
+HU_WINDOWS = {1: [(-110.0, 190.0)], 3: [(l - w // 2, l + w // 2) for l, w in ((40, 80), (80, 200), (600, 2800))]}
+
+
+def window_hu(hu: torch.Tensor, in_channels: int = 1, out_dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """HU volumes [B, 1, ...] (fp32 or fp16) -> windowed [B, in_channels, ...] in [0, 1]: the windowing step of
+    `loading_transforms` (src/data/transforms.py:108-133) on the device, cast to the cache's fp16 by default."""
+    from . import _lib
+    lib = _lib.load()
+    if not hu.is_cuda:
+        raise _lib.HctError("window_hu runs on the GPU (libheadct_hip); no CPU fallback exists")
+    if in_channels not in HU_WINDOWS:
+        raise NotImplementedError(f"Channel size {in_channels} is not implemented.")
+    if hu.dtype not in (torch.float32, torch.float16):
+        hu = hu.float()
+    hu = hu.contiguous()
+    B, vox = hu.shape[0], hu[0].numel()
+    lo = torch.tensor([w[0] for w in HU_WINDOWS[in_channels]], dtype=torch.float32, device=hu.device)
+    hi = torch.tensor([w[1] for w in HU_WINDOWS[in_channels]], dtype=torch.float32, device=hu.device)
+    out = torch.empty((B, in_channels) + tuple(hu.shape[2:]), dtype=out_dtype, device=hu.device)
+    code = {torch.float16: _lib.HCT_F16, torch.float32: _lib.HCT_F32}
+    with torch.cuda.device(hu.device):
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.hct_hu_window(hu.data_ptr(), code[hu.dtype], out.data_ptr(), code[out_dtype], B, vox, in_channels,
+                                     lo.data_ptr(), hi.data_ptr(), st), "hct_hu_window")
+    return out
+
+
 class SyntheticVolumes:
     """A fixed pool of `n_batches` pre-generated [B,C,S,S,S] batches on `device`, cycled (len == n_batches)."""
 

@@ -216,6 +216,13 @@ int hct_head_linear_wgrad(const float* x, const float* mean, const float* var, f
  *   out[b, c, i, j, k] = (float)in[b, c, f0(i), f1(j), f2(k)] + shift[b],   f_a(t) = S-1-t if flip[b] bit a else t.
  * in: [B, C, S, S, S] of in_dtype (HCT_F16 / HCT_BF16 / HCT_F32), out fp32 (may not alias in).  flip / shift may be NULL.
  * RandGaussianSmoothd (transforms.py:230-238) is not part of this call. */
+/* HU windowing of loading_transforms (src/data/transforms.py:108-133): ScaleIntensityRanged(a_min, a_max, 0, 1, clip) for one
+ * channel (window 40 +- 150), MultipleWindowScaleStack (transforms.py:8-36) for three ((40,80), (80,200), (600,2800) as
+ * centre, width -> a_min = l - w/2, a_max = l + w/2), stacked on the channel axis:
+ *   out[b, w, v] = clip((hu[b, v] - a_min[w]) / (a_max[w] - a_min[w]), 0, 1),   hu [B, voxels] -> out [B, n_windows, voxels].
+ * in / out dtype HCT_F32 or HCT_F16 (fp16 = the persistent cache's type, transforms.py:171-178); a_min / a_max device fp32. */
+int hct_hu_window(const void* hu, int in_dtype, void* out, int out_dtype, int B, int64_t voxels, int n_windows, const float* a_min,
+                  const float* a_max, void* stream);
 int hct_augment_volume(const void* in, int in_dtype, float* out, int B, int C, int S, const unsigned char* flip,
                        const float* shift, void* stream);
 

@@ -219,6 +219,27 @@ def augment_volume(x: torch.Tensor, flip: Optional[Sequence[int]] = None, shift:
     return out
 
 
+def hu_window(hu: torch.Tensor, in_channels: int = 1) -> torch.Tensor:
+    """Windowing step of loading_transforms (src/data/transforms.py:108-133): one channel = ScaleIntensityRanged(a_min 40-150,
+    a_max 40+150, b 0..1, clip); three = MultipleWindowScaleStack (:8-36) over (centre, width) (40,80), (80,200), (600,2800)
+    with a_min = l - w // 2, a_max = l + w // 2, concatenated on the channel axis.  MONAI's ScaleIntensityRange computes
+    (img - a_min) / (a_max - a_min) * (b_max - b_min) + b_min and clips to [b_min, b_max] in fp32 (stated from knowledge of
+    MONAI 1.2 / 1.3: MONAI is not installed here, so parity with MONAI itself is unpinned).  hu [B, 1, ...] -> [B, C, ...]."""
+    if in_channels == 1:
+        wins = [(40 - 150, 40 + 150)]
+    elif in_channels == 3:
+        wins = [(l - w // 2, l + w // 2) for l, w in ((40, 80), (80, 200), (600, 2800))]
+    else:
+        raise NotImplementedError(f"Channel size {in_channels} is not implemented.")
+    x = hu.float()
+    outs = []
+    for a_min, a_max in wins:
+        y = (x - float(a_min)) / float(a_max - a_min)
+        y = y * (1.0 - 0.0) + 0.0
+        outs.append(torch.clamp(y, 0.0, 1.0))
+    return torch.cat(outs, dim=1)
+
+
 def hash_uniform(n: int, seed: int) -> np.ndarray:
     """Portable deterministic U[-1,1) stream (integer hash; independent of any RNG library)."""
     i = np.arange(n, dtype=np.uint64)
@@ -317,6 +338,18 @@ def random_masking_from_noise(cfg: MAEConfig, noise: torch.Tensor):
     return ids_shuffle, ids_restore, ids_keep, mask
 
 
+# bf16-storage emulation (tests only): with `emulate_bf16` the restatement rounds to bfloat16 exactly where the HIP path's bf16
+# mode stores bfloat16 -- GEMM operand copies of the weights, LayerNorm outputs, qkv, softmax probabilities, attention output,
+# pre-GELU / GELU activations, patch rows, tokens, latent, decoder input rows, prediction -- and keeps fp32 everywhere the HIP
+# path does (residual stream, statistics, loss, master weights, gradients of parameters).  Comparing the HIP bf16 path with
+# THIS oracle isolates logic from rounding: what is left is accumulation order and the rounding of backward intermediates.
+_EMU = [False]
+
+
+def _r(t: torch.Tensor) -> torch.Tensor:
+    return t.bfloat16().float() if _EMU[0] else t
+
+
 def _layer_norm(x, w, b):
     return F.layer_norm(x, (x.shape[-1],), w, b, 1e-5)  # nn.LayerNorm default eps (attentionblock.py:92-93)
 
@@ -324,34 +357,42 @@ def _layer_norm(x, w, b):
 def _block(p: Dict[str, torch.Tensor], prefix: str, h: torch.Tensor, heads: int, inter: Optional[dict], tag: str):
     """AttentionBlock.forward attentionblock.py:96-99; SelfAttention.forward :51-66; MONAI MLPBlock (exact-erf GELU)."""
     B, N, D = h.shape
-    x1 = _layer_norm(h, p[f"{prefix}.att_norm.weight"], p[f"{prefix}.att_norm.bias"])
-    qkv = F.linear(x1, p[f"{prefix}.attn.qkv.weight"], p.get(f"{prefix}.attn.qkv.bias"))
+    x1 = _r(_layer_norm(h, p[f"{prefix}.att_norm.weight"], p[f"{prefix}.att_norm.bias"]))
+    qkv = _r(F.linear(x1, _r(p[f"{prefix}.attn.qkv.weight"]), p.get(f"{prefix}.attn.qkv.bias")))
     qkv = qkv.reshape(B, N, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     att = torch.softmax((q @ k.transpose(-1, -2)) * (D // heads) ** -0.5, dim=-1)  # SDPA, no mask, dropout 0 (:61)
-    y = (att @ v).transpose(1, 2).contiguous().view(B, N, D)
-    y = F.linear(y, p[f"{prefix}.attn.proj.weight"], p[f"{prefix}.attn.proj.bias"])
+    y = _r((_r(att) @ v).transpose(1, 2).contiguous().view(B, N, D))
+    y = F.linear(y, _r(p[f"{prefix}.attn.proj.weight"]), p[f"{prefix}.attn.proj.bias"])
     h = h + y
-    x2 = _layer_norm(h, p[f"{prefix}.ffn_norm.weight"], p[f"{prefix}.ffn_norm.bias"])
-    u = F.linear(x2, p[f"{prefix}.mlp.linear1.weight"], p[f"{prefix}.mlp.linear1.bias"])
-    gact = F.gelu(u)  # nn.GELU() default = exact erf
-    h = h + F.linear(gact, p[f"{prefix}.mlp.linear2.weight"], p[f"{prefix}.mlp.linear2.bias"])
+    x2 = _r(_layer_norm(h, p[f"{prefix}.ffn_norm.weight"], p[f"{prefix}.ffn_norm.bias"]))
+    u = F.linear(x2, _r(p[f"{prefix}.mlp.linear1.weight"]), p[f"{prefix}.mlp.linear1.bias"])
+    gact = _r(F.gelu(u))  # nn.GELU() default = exact erf
+    h = h + F.linear(gact, _r(p[f"{prefix}.mlp.linear2.weight"]), p[f"{prefix}.mlp.linear2.bias"])
     if inter is not None:
         inter[f"{tag}.out"] = h
     return h
 
 
 def forward(cfg: MAEConfig, p: Dict[str, torch.Tensor], x: torch.Tensor, noise: torch.Tensor,
-            want_inter: bool = False):
+            want_inter: bool = False, emulate_bf16: bool = False):
     """MaskedAutoencoderViT.forward src/models/mae.py:303-317.  Returns (loss, pred, mask, inter)."""
+    _EMU[0] = bool(emulate_bf16)
+    try:
+        return _forward(cfg, p, x, noise, want_inter)
+    finally:
+        _EMU[0] = False
+
+
+def _forward(cfg: MAEConfig, p: Dict[str, torch.Tensor], x: torch.Tensor, noise: torch.Tensor, want_inter: bool = False):
     inter: Optional[dict] = {} if want_inter else None
     B = x.shape[0]
     D, Dd, L, K = cfg.encoder_embed_dim, cfg.decoder_embed_dim, cfg.num_patches, cfg.len_keep
     P = cfg.patch_size
     # --- forward_encoder mae.py:220-242 ---
     # PatchEmbeddingBlock.forward patch_embedding.py:149-156: Conv3d(k=s=P) -> flatten(2).transpose -> + pos
-    tok = F.conv3d(x, p["patch_embedding.patch_embeddings.weight"], p["patch_embedding.patch_embeddings.bias"], stride=P)
-    tok = tok.flatten(2).transpose(-1, -2)
+    tok = F.conv3d(_r(x), _r(p["patch_embedding.patch_embeddings.weight"]), p["patch_embedding.patch_embeddings.bias"], stride=P)
+    tok = _r(tok.flatten(2).transpose(-1, -2))
     if "patch_embedding.position_embeddings" in p:
         tok = tok + p["patch_embedding.position_embeddings"]
     ids_shuffle, ids_restore, ids_keep, mask = random_masking_from_noise(cfg, noise)
@@ -361,9 +402,9 @@ def forward(cfg: MAEConfig, p: Dict[str, torch.Tensor], x: torch.Tensor, noise: 
         inter.update(patch_embed=tok, ids_restore=ids_restore, ids_keep=ids_keep, mask=mask, enc_in=h)
     for i in range(cfg.encoder_depth):
         h = _block(p, f"blocks.{i}", h, cfg.encoder_num_heads, inter, f"enc{i}")
-    latent = _layer_norm(h, p["norm.weight"], p["norm.bias"])  # mae.py:240
+    latent = _r(_layer_norm(h, p["norm.weight"], p["norm.bias"]))  # mae.py:240
     # --- forward_decoder mae.py:244-275 ---
-    y = F.linear(latent, p["decoder_embed.weight"], p.get("decoder_embed.bias"))
+    y = _r(F.linear(latent, _r(p["decoder_embed.weight"]), p.get("decoder_embed.bias")))
     mask_tokens = p["mask_token"].repeat(B, L + 1 - y.shape[1], 1)
     y_ = torch.cat([y[:, 1:, :], mask_tokens], dim=1)
     y_ = torch.gather(y_, 1, ids_restore.unsqueeze(-1).repeat(1, 1, Dd))
@@ -374,8 +415,8 @@ def forward(cfg: MAEConfig, p: Dict[str, torch.Tensor], x: torch.Tensor, noise: 
         inter.update(latent=latent, dec_in=y)
     for i in range(cfg.decoder_depth):
         y = _block(p, f"decoder_blocks.{i}", y, cfg.decoder_num_heads, inter, f"dec{i}")
-    y = _layer_norm(y, p["decoder_norm.weight"], p["decoder_norm.bias"])
-    pred = F.linear(y, p["decoder_pred.weight"], p.get("decoder_pred.bias"))[:, 1:, :]
+    y = _r(_layer_norm(y, p["decoder_norm.weight"], p["decoder_norm.bias"]))
+    pred = _r(F.linear(y, _r(p["decoder_pred.weight"]), p.get("decoder_pred.bias")))[:, 1:, :]
     # --- forward_loss mae.py:277-301 ---
     target = patchify(cfg, x)
     if cfg.norm_pix_loss:
@@ -488,11 +529,11 @@ def attention_classifier_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, nu
 
 
 def forward_backward(cfg: MAEConfig, params: Dict[str, torch.Tensor], x: torch.Tensor, noise: torch.Tensor,
-                     want_inter: bool = False):
+                     want_inter: bool = False, emulate_bf16: bool = False):
     """loss + autograd gradients of every trainable parameter (engine_pretrain_mae.py:58-62, AMP off)."""
     frozen = {n for n, _, rg in param_shapes(cfg) if not rg}
     p = {k: (v.clone().requires_grad_(k not in frozen)) for k, v in params.items()}
-    loss, pred, mask, inter = forward(cfg, p, x, noise, want_inter)
+    loss, pred, mask, inter = forward(cfg, p, x, noise, want_inter, emulate_bf16=emulate_bf16)
     loss.backward()
     grads = {k: v.grad for k, v in p.items() if v.grad is not None}
     return loss.detach(), pred.detach(), mask, grads, ({k: v.detach() for k, v in inter.items()} if inter else None)
@@ -546,10 +587,10 @@ class TrainState:
 
 def train_step(cfg: MAEConfig, st: TrainState, x: torch.Tensor, noise: torch.Tensor, *, base_lr: float,
                min_lr: float, warmup: int, total: int, weight_decay: float, beta1: float = 0.9,
-               beta2: float = 0.95, grad_clip: float = 0.0):
+               beta2: float = 0.95, grad_clip: float = 0.0, emulate_bf16: bool = False):
     """One iteration of train_one_epoch (engine_pretrain_mae.py:52-71), AMP disabled:
     zero_grad -> forward -> backward -> per-param clip -> AdamW(lr_t) -> scheduler.step()."""
-    loss, pred, mask, grads, _ = forward_backward(cfg, st.params, x, noise)
+    loss, pred, mask, grads, _ = forward_backward(cfg, st.params, x, noise, emulate_bf16=emulate_bf16)
     norms = clip_gradients_(grads, grad_clip) if grad_clip else {}
     lr = base_lr * cosine_warmup_lambda(st.step, warmup, total, base_lr, min_lr)  # LambdaLR: lr at step index
     st.step += 1

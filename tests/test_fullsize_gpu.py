@@ -115,3 +115,42 @@ def test_vitl_shapes_cut_depth_vs_oracle(lib, cuda):
     assert rel_err(model.last_pred(B), o_pred) < 2e-2
     bad = [(rel_err(grads[k], o_grads[k]), k) for k in grads if not k.endswith("qkv.bias")]
     assert max(bad)[0] < 6e-2, sorted(bad)[-5:]
+
+
+def test_vitl_full_depth_step_properties(lib, cuda):
+    """BASELINE config #4 at FULL depth (ViT-L/16^3 on 128^3: 24 encoder blocks of D=1024 / 16 heads / MLP 4096 on 129 tokens,
+    8 decoder blocks of 768 / 16 heads on 513 tokens, learnable position table) -- the `bench.py --config vitl` workload at
+    B=16.  Too large for the oracle, so: bit-reproducible step, loss and gradients of the B=16 step equal to the mean of its two
+    B=8 halves, masking structure, and a full optimizer step that lowers the loss on the same batch."""
+    from headct_foundation_amd.optim import HipAdamW, clip_gradients
+    cfg = O.CONFIGS["vitl"]
+    B, S = 16, cfg.input_size
+    L = (S // cfg.patch_size) ** 3
+    params = O.make_params(cfg, 11)
+    g = torch.Generator(device=cuda)
+    g.manual_seed(17)
+    x = torch.rand(B, 1, S, S, S, device=cuda, generator=g)
+    noise = torch.rand(B, L, device=cuda, generator=g)
+    model = build_hip_model(cfg, params, cuda, "bf16").train()
+    loss1, g1 = _step(model, x, noise)
+    loss2, g2 = _step(model, x, noise)
+    assert loss1 == loss2 and all(torch.equal(g1[k], g2[k]) for k in g1), "the ViT-L step is not bit-reproducible"
+    K = int(L * (1 - cfg.mask_ratio))
+    assert model.len_keep == K == 128
+    mask = model.last_mask(B)
+    ids_restore = model.activation("ids_restore", B).long()
+    assert float(mask.sum()) == B * (L - K)
+    assert torch.equal(torch.sort(ids_restore, dim=1).values, torch.arange(L, device=cuda).expand(B, L))
+    assert torch.equal(mask == 0, ids_restore < K)
+    half = build_hip_model(cfg, params, cuda, "bf16").train()
+    la, ga = _step(half, x[:8], noise[:8])
+    lb, gb = _step(half, x[8:], noise[8:])
+    assert abs(loss1 - 0.5 * (la + lb)) < 2e-5 * abs(loss1)
+    worst = max((rel_err(g1[k], 0.5 * (ga[k] + gb[k])), k) for k in g1 if not k.endswith("qkv.bias"))
+    assert worst[0] < 5e-3, worst
+    del half
+    opt = HipAdamW(model, lr=1e-4, weight_decay=5e-3, betas=(0.9, 0.95))
+    clip_gradients(model, 3.0)
+    opt.step()
+    loss3, _ = _step(model, x, noise)
+    assert loss3 < loss1, (loss1, loss3)

@@ -353,3 +353,23 @@ def test_augment_volume_vs_oracle(lib, cuda, dtype):
     f, sft = aug.last_draw
     assert torch.equal(y.cpu(), O.augment_volume(x.cpu(), f.tolist(), sft.tolist()))
     assert float(sft.abs().max()) <= 0.1
+
+
+@pytest.mark.parametrize("channels", [1, 3])
+def test_hu_window_vs_oracle(lib, cuda, channels):
+    """HU windowing of loading_transforms (transforms.py:108-133) on the device: bit-equal to the oracle's fp32 restatement, and
+    equal to it after the cache's fp16 cast; window edges, values far outside and fp16 HU input included.  (Parity with MONAI's
+    ScaleIntensityRange itself is unpinned: MONAI is not installed.)"""
+    from headct_foundation_amd.data import window_hu
+    from oracle import mae_oracle as O
+    g = torch.Generator(device="cpu").manual_seed(3)
+    hu = (torch.rand(2, 1, 8, 12, 16, generator=g) * 4000 - 1200).round()
+    hu.view(-1)[:12] = torch.tensor([-110., 190., -111., 191., 0., 80., -20., 180., -800., 2000., -3000., 5000.])
+    want = O.hu_window(hu, channels)
+    got32 = window_hu(hu.to(cuda), channels, out_dtype=torch.float32)
+    assert got32.shape == want.shape and torch.equal(got32.cpu(), want)
+    got16 = window_hu(hu.to(cuda), channels)
+    assert got16.dtype == torch.float16 and torch.equal(got16.cpu(), want.half())
+    got_h = window_hu(hu.half().to(cuda), channels, out_dtype=torch.float32)  # integer HU up to 2048 are exact in fp16
+    assert torch.equal(got_h.cpu(), O.hu_window(hu.half().float(), channels))
+    assert float(got32.min()) == 0.0 and float(got32.max()) == 1.0
