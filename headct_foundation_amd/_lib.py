@@ -82,6 +82,11 @@ _PROTOS = {
     "hct_batchnorm_stats": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hct_softmax_xent": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hct_head_linear_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "hct_dino_loss_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "hct_dino_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_size_t, c_void_p]),
+    "hct_dino_center_update": (c_int, [c_void_p, c_void_p, c_int, C.c_double, C.c_double, c_void_p]),
+    "hct_ema_update": (c_int, [c_void_p, c_void_p, c_int64, C.c_double, c_void_p]),
     "hct_hu_window": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "hct_augment_volume": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "hct_pos_embed_interp3d": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),

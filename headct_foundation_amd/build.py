@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libheadct_hip.so")
 SOURCES = ["elementwise.hip", "optim.hip", "gemm.hip", "attention_simple.hip", "attention_mfma.hip", "attention.hip",
-           "mae_plan.hip", "heads.hip", "prof.hip"]
+           "mae_plan.hip", "heads.hip", "prof.hip", "dino.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "prof.h"), os.path.join(os.path.dirname(HERE), "include", "headct_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-inline-asm", "-ffp-contract=off"]
 

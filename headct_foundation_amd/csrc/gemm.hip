@@ -614,6 +614,7 @@ __device__ __forceinline__ void dma16(i32x4 rsrc, uint32_t lds_base, uint32_t vo
 // when the workgroup exits.
 #ifdef HCT_STAMPS
 __device__ uint32_t* g_stamp_ptr = nullptr;
+__device__ uint32_t g_stamp_words = 0;  // capacity of the stamp buffer: the only raw-pointer store of the diagnostic build is bounded by it
 #define HCT_STAMP(k)                                                                                   \
   do {                                                                                                 \
     unsigned long long t_;                                                                             \
@@ -855,7 +856,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     if (!more) break;
   }
 #ifdef HCT_STAMPS
-  if (g_stamp_ptr && wave == 0) g_stamp_ptr[blockIdx.x * 64 + lane] = stamps;
+  if (g_stamp_ptr && wave == 0 && blockIdx.x * 64 + lane < g_stamp_words) g_stamp_ptr[blockIdx.x * 64 + lane] = stamps;
 #endif
 }
 
@@ -1534,7 +1535,8 @@ void hct_debug_set_gemm_variant(int v) {
   g_nt_variant = v;
 }
 #ifdef HCT_STAMPS
-int hct_debug_set_stamp_buffer(void* p) {  // >= 64 * grid uint32 (diagnostic build only)
+int hct_debug_set_stamp_buffer(void* p, unsigned int n_words) {  // 64 uint32 per workgroup (diagnostic build only)
+  if (int rc = hct::check_hip(hipMemcpyToSymbol(HIP_SYMBOL(hct::g_stamp_words), &n_words, sizeof(n_words)), "stamp buffer size")) return rc;
   return hct::check_hip(hipMemcpyToSymbol(HIP_SYMBOL(hct::g_stamp_ptr), &p, sizeof(p)), "stamp buffer");
 }
 #endif

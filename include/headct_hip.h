@@ -216,6 +216,22 @@ int hct_head_linear_wgrad(const float* x, const float* mean, const float* var, f
  *   out[b, c, i, j, k] = (float)in[b, c, f0(i), f1(j), f2(k)] + shift[b],   f_a(t) = S-1-t if flip[b] bit a else t.
  * in: [B, C, S, S, S] of in_dtype (HCT_F16 / HCT_BF16 / HCT_F32), out fp32 (may not alias in).  flip / shift may be NULL.
  * RandGaussianSmoothd (transforms.py:230-238) is not part of this call. */
+/* ------------------------------------------------------------------------------------------
+ * DINO self-distillation (BASELINE config #5; reference engine_pretrain_dino.py:14-130).
+ *   hct_dino_loss: DINOLoss.forward, src/losses/losses.py:63-91, plus the gradient w.r.t. the student logits and the column
+ *     sums of the teacher logits that update_center (:93-102) all-reduces.  student [V*B, K] (crop-major: row v*B + b),
+ *     teacher [2*B, K], both `dtype`; center [K] fp32; loss: 1 device fp32.  dstudent (same shape / dtype as student) and
+ *     batch_center_sum [K] may be NULL; dloss: device scalar multiplying the gradient, or NULL for 1.
+ *   hct_dino_center_update: center = center * momentum + (batch_center_sum / count) * (1 - momentum), count = 2*B*world.
+ *   hct_ema_update: momentum encoder, src/utils/misc.py:386-397: k = k * m + (1 - m) * q over a flat fp32 buffer.
+ * ------------------------------------------------------------------------------------------ */
+size_t hct_dino_loss_workspace_bytes(int n_crops, int B, int K);
+int hct_dino_loss(const void* student, const void* teacher, int dtype, int n_crops, int B, int K, const float* center, float student_temp,
+                  float teacher_temp, float* loss, void* dstudent, const float* dloss, float* batch_center_sum, void* workspace,
+                  size_t workspace_bytes, void* stream);
+int hct_dino_center_update(float* center, const float* batch_center_sum, int K, double momentum, double count, void* stream);
+int hct_ema_update(float* momentum_params, const float* params, int64_t n, double m, void* stream);
+
 /* HU windowing of loading_transforms (src/data/transforms.py:108-133): ScaleIntensityRanged(a_min, a_max, 0, 1, clip) for one
  * channel (window 40 +- 150), MultipleWindowScaleStack (transforms.py:8-36) for three ((40,80), (80,200), (600,2800) as
  * centre, width -> a_min = l - w/2, a_max = l + w/2), stacked on the channel axis:

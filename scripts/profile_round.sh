@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round profile on the GPU box: kernel trace + PMC passes of the bench workload (summaries are copied to profiles/ by hand).
+#   bash scripts/profile_round.sh r02
+set -e
+TAG=${1:-r02}
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/${TAG}_prof
+mkdir -p $OUT
+BENCH="python3 $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $BENCH > $OUT/kt.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/mfma -o mfma -- $BENCH > $OUT/mfma.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $OUT/valu -o valu -- $BENCH > $OUT/valu.log 2>&1 || true
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o fetch -- $BENCH > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o write -- $BENCH > $OUT/write.log 2>&1
+find $OUT -name "*.csv" | xargs ls -la
+# keep what merges back small: the per-dispatch traces are summarised here
+python3 $PWD/scripts/summarize_round.py $OUT $PWD/gpurun_out/${TAG}_summary.json || true
+find $OUT -name "*kernel_trace.csv" -size +8M -delete

@@ -14,9 +14,9 @@ _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"libheadct_hip_{os
 from headct_foundation_amd._lib import HCT_BF16, HCT_F32, GemmArgs
 lib = _lib.load(); dev = torch.device("cuda"); st = torch.cuda.current_stream().cuda_stream
 lib.hct_debug_set_stamp_buffer.restype = C.c_int
-lib.hct_debug_set_stamp_buffer.argtypes = [C.c_void_p]
+lib.hct_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_uint]
 stamps = torch.zeros(256 * 64, dtype=torch.int32, device=dev)
-_lib.check(lib.hct_debug_set_stamp_buffer(stamps.data_ptr()), "stamp buffer")
+_lib.check(lib.hct_debug_set_stamp_buffer(stamps.data_ptr(), stamps.numel()), "stamp buffer")
 
 
 def call(name, M, N, K, out_f32=False, bias=False, residual=False, act=0, stagger=-1):

@@ -404,6 +404,85 @@ def pos_interp_fixture():
         json.dump(out, f)
 
 
+def dino_fixture():
+    """DINOLoss (src/losses/losses.py:46-102), _update_momentum_encoder (src/utils/misc.py:386-397), wd_cosine_scheduler
+    (src/utils/wd_sched.py:3-15) and DINOHead (src/models/dino_head.py:7-41) of the reference on hash-generated inputs; the
+    oracle restatement (oracle/dino_oracle.py) is asserted equal here, the reference's outputs are the fixture."""
+    import torch.distributed as dist
+    from oracle import dino_oracle as D
+    from src.losses.losses import DINOLoss
+    from src.models.dino_head import DINOHead
+    from src.utils.misc import _update_momentum_encoder
+    from src.utils.wd_sched import wd_cosine_scheduler
+    out = {}
+    V, B, K = 4, 3, 512
+    u = lambda shape, seed, lo, hi: torch.from_numpy(O.hash_uniform(int(np.prod(shape)), seed)).float().reshape(shape) * (hi - lo) + lo
+    student = u((V * B, K), 501, -3.0, 3.0).requires_grad_(True)
+    teacher = u((2 * B, K), 502, -3.0, 3.0)
+    center0 = u((1, K), 503, -0.5, 0.5)
+    crit = DINOLoss(K, V, 0.04, 0.07, 3, 10, student_temp=0.1, center_momentum=0.9)
+    crit.center.copy_(center0)
+    real_ar, real_ws = dist.all_reduce, dist.get_world_size
+    dist.all_reduce, dist.get_world_size = (lambda t, *a, **k: None), (lambda *a, **k: 1)
+    try:
+        loss = crit(student, teacher, 1)  # epoch 1 of the warm-up: teacher temperature 0.055
+    finally:
+        dist.all_reduce, dist.get_world_size = real_ar, real_ws
+    loss.backward()
+    temp = float(crit.teacher_temp_schedule[1])
+    o_loss = D.dino_loss(student.detach(), teacher, center0, V, 0.1, temp)
+    assert abs(float(o_loss) - float(loss)) < 1e-6 * abs(float(loss)), (float(o_loss), float(loss))
+    assert torch.allclose(D.update_center(center0, teacher, 0.9), crit.center, rtol=0, atol=0)
+    assert np.array_equal(D.teacher_temp_schedule(0.04, 0.07, 3, 10), crit.teacher_temp_schedule)
+    out["loss"] = dict(V=V, B=B, K=K, student_seed=501, teacher_seed=502, center_seed=503, student_temp=0.1, teacher_temp=temp,
+                       center_momentum=0.9, loss=float(loss), dstudent=sample(student.grad, 256), center_after=sample(crit.center, 128),
+                       teacher_temp_schedule=crit.teacher_temp_schedule.tolist())
+    # momentum teacher
+    q = [u((5, 7), 510, -1, 1), u((12,), 511, -1, 1)]
+    k = [u((5, 7), 512, -1, 1), u((12,), 513, -1, 1)]
+    mq, mk = nn.ParameterList([nn.Parameter(t.clone()) for t in q]), nn.ParameterList([nn.Parameter(t.clone()) for t in k])
+    _update_momentum_encoder(mq, mk, 0.996)
+    ko = [t.clone() for t in k]
+    D.update_momentum_encoder(q, ko, 0.996)
+    assert all(torch.equal(a, b.data) for a, b in zip(ko, mk))
+    out["ema"] = dict(m=0.996, q_seeds=[510, 511], k_seeds=[512, 513], shapes=[[5, 7], [12]], k_after=[t.data.flatten().tolist() for t in mk])
+    # schedules
+    wd = wd_cosine_scheduler(0.04, 0.4, 5, 7)
+    mom = wd_cosine_scheduler(0.996, 1.0, 5, 7)
+    assert np.array_equal(D.cosine_scheduler(0.04, 0.4, 5, 7), wd)
+    out["schedules"] = dict(wd=dict(base=0.04, final=0.4, epochs=5, niter=7, values=wd.tolist()),
+                            momentum=dict(base=0.996, final=1.0, epochs=5, niter=7, values=mom.tolist()),
+                            warm=dict(base=1.0, final=0.1, epochs=4, niter=3, warmup_epochs=1, start=0.2,
+                                      values=wd_cosine_scheduler(1.0, 0.1, 4, 3, 1, 0.2).tolist()))
+    # projection head: forward + backward through every parameter (weight_g frozen: norm_last_layer)
+    head = DINOHead(48, 128, use_bn=False, norm_last_layer=True, nlayers=3, hidden_dim=64, bottleneck_dim=32)
+    hp = {}
+    for i, (n, prm) in enumerate(head.named_parameters()):
+        lo, hi = (-0.2, 0.2) if prm.dim() > 1 else (-0.05, 0.05)
+        if n.endswith("weight_g"):
+            continue  # filled with 1 by the constructor (dino_head.py:27)
+        prm.data.copy_(u(tuple(prm.shape), 520 + i, lo, hi))
+    for n, prm in head.named_parameters():
+        hp[n] = prm.detach().clone()
+    xh = u((6, 48), 540, -1, 1).requires_grad_(True)
+    dy = u((6, 128), 541, -1, 1)
+    y = head(xh)
+    (y * dy).sum().backward()
+    xo = xh.detach().clone().requires_grad_(True)
+    po = {n: t.clone().requires_grad_(not n.endswith("weight_g")) for n, t in hp.items()}
+    yo = D.dino_head_forward(po, xo)
+    (yo * dy).sum().backward()
+    assert torch.allclose(yo, y, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(xo.grad, xh.grad, rtol=1e-5, atol=1e-7)
+    out["head"] = dict(in_dim=48, out_dim=128, hidden=64, bottleneck=32, names=[n for n, _ in head.named_parameters()],
+                       shapes={n: list(t.shape) for n, t in hp.items()}, param_seed0=520, x_seed=540, dy_seed=541,
+                       requires_grad={n: bool(prm.requires_grad) for n, prm in head.named_parameters()},
+                       y=sample(y, 256), dx=sample(xh.grad, 256),
+                       grads={n: sample(prm.grad, 128) for n, prm in head.named_parameters() if prm.grad is not None})
+    with open(os.path.join(HERE, "dino.json"), "w") as f:
+        json.dump(out, f)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted: fixtures can only be regenerated in the build container"
     sys.dont_write_bytecode = True
@@ -411,11 +490,16 @@ if __name__ == "__main__":
     sys.path.insert(0, REF)
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if "dino" in sys.argv[1:]:  # python tests/golden/make_golden.py dino : only tests/golden/dino.json
+        dino_fixture()
+        print("dino fixture written")
+        sys.exit(0)
     sincos_fixture()
     lr_schedule_fixture()
     pos_interp_fixture()
     vit_fixture()
     classifier_fixture()
+    dino_fixture()
     run_case("micro", 2, 0, full=True)
     run_case("yaml_cut", 2, 1, full=False)
     run_case("tiny", 2, 0, full=False)

@@ -214,3 +214,42 @@ def test_linear_probe_step_oracle_matches_reference_fixture():
     assert close(logits, e["logits"]) and abs(float(loss) - e["loss"]) < 2e-6
     assert close(grads["linear.weight"], e["grad_weight"]) and close(grads["linear.bias"], e["grad_bias"])
     assert close(stats["bn.running_mean"], e["running_mean"]) and close(stats["bn.running_var"], e["running_var"])
+
+
+def _hu(shape, seed, lo, hi):
+    import numpy as np
+    return torch.from_numpy(O.hash_uniform(int(np.prod(shape)), seed)).float().reshape(shape) * (hi - lo) + lo
+
+
+def test_dino_oracle_vs_reference_fixture():
+    """oracle/dino_oracle.py against tests/golden/dino.json (outputs of the reference's DINOLoss, _update_momentum_encoder,
+    wd_cosine_scheduler and DINOHead on hash-generated inputs)."""
+    import json, os
+    import numpy as np
+    from oracle import dino_oracle as D
+    from tests.util import GOLDEN, sample_of
+    fx = json.load(open(os.path.join(GOLDEN, "dino.json")))
+    L = fx["loss"]
+    student = _hu((L["V"] * L["B"], L["K"]), L["student_seed"], -3.0, 3.0).requires_grad_(True)
+    teacher, center = _hu((2 * L["B"], L["K"]), L["teacher_seed"], -3.0, 3.0), _hu((1, L["K"]), L["center_seed"], -0.5, 0.5)
+    loss = D.dino_loss(student, teacher, center, L["V"], L["student_temp"], L["teacher_temp"])
+    loss.backward()
+    assert abs(float(loss) - L["loss"]) < 1e-6 * abs(L["loss"])
+    got, want, _, _ = sample_of(student.grad, L["dstudent"])
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-9)
+    got, want, _, _ = sample_of(D.update_center(center, teacher, L["center_momentum"]), L["center_after"])
+    assert torch.equal(got, want)
+    assert np.array_equal(D.teacher_temp_schedule(0.04, 0.07, 3, 10), np.array(L["teacher_temp_schedule"]))
+    E = fx["ema"]
+    q = [_hu(tuple(s), sd, -1, 1) for s, sd in zip(E["shapes"], E["q_seeds"])]
+    k = [_hu(tuple(s), sd, -1, 1) for s, sd in zip(E["shapes"], E["k_seeds"])]
+    D.update_momentum_encoder(q, k, E["m"])
+    for t, want in zip(k, E["k_after"]):
+        assert torch.equal(t.flatten(), torch.tensor(want))
+    for key in ("wd", "momentum"):
+        S = fx["schedules"][key]
+        assert np.array_equal(D.cosine_scheduler(S["base"], S["final"], S["epochs"], S["niter"]), np.array(S["values"]))
+    S = fx["schedules"]["warm"]
+    assert np.array_equal(D.cosine_scheduler(S["base"], S["final"], S["epochs"], S["niter"], S["warmup_epochs"], S["start"]), np.array(S["values"]))
+    from headct_foundation_amd.dino import wd_cosine_scheduler
+    assert np.array_equal(wd_cosine_scheduler(S["base"], S["final"], S["epochs"], S["niter"], S["warmup_epochs"], S["start"]), np.array(S["values"]))
