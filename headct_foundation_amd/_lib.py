@@ -39,6 +39,7 @@ class MaeConfig(C.Structure):
         ("encoder_depth", c_int), ("encoder_embed_dim", c_int), ("encoder_mlp_dim", c_int), ("encoder_num_heads", c_int),
         ("decoder_depth", c_int), ("decoder_embed_dim", c_int), ("decoder_mlp_dim", c_int), ("decoder_num_heads", c_int),
         ("norm_pix_loss", c_int), ("use_bias", c_int),
+        ("encoder_only", c_int), ("num_register_tokens", c_int), ("final_norm_eps", c_float),
     ]
 
 
@@ -87,6 +88,10 @@ _PROTOS = {
                               c_void_p, c_size_t, c_void_p]),
     "hct_dino_center_update": (c_int, [c_void_p, c_void_p, c_int, C.c_double, C.c_double, c_void_p]),
     "hct_ema_update": (c_int, [c_void_p, c_void_p, c_int64, C.c_double, c_void_p]),
+    "hct_l2norm_rows_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "hct_l2norm_rows_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "hct_weight_norm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "hct_weight_norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "hct_hu_window": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "hct_augment_volume": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "hct_pos_embed_interp3d": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -119,6 +124,9 @@ _PROTOS = {
     "hct_mae_num_backward_stages": (c_int, [c_void_p]),
     "hct_mae_backward_stage_range": (c_int, [c_void_p, c_int, C.POINTER(c_int64), C.POINTER(c_int64)]),
     "hct_mae_backward_stage": (c_int, [c_void_p, c_int, c_void_p]),
+    "hct_vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "hct_vit_backward_stage": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "hct_vit_assemble_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hct_mae_plan_activation": (c_void_p, [c_void_p, C.c_char_p, C.POINTER(c_int64), C.POINTER(c_int64), C.POINTER(c_int)]),
 }
 

@@ -137,6 +137,79 @@ __global__ void __launch_bounds__(256) ema_update_kernel(float* __restrict__ k, 
   }
 }
 
+// ---- projection-head pieces (src/models/dino_head.py:37-41): one wave per row, n a multiple of 4 --------------------------
+// F.normalize(z, dim=-1, p=2): zn = z / max(||z||, 1e-12)
+template <typename T>
+__global__ void __launch_bounds__(256) l2norm_rows_fwd_kernel(const float* __restrict__ z, int M, int n, T* __restrict__ zn, float* __restrict__ inv_norm) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* src = z + (size_t)row * n;
+  float ss = 0.f;
+  for (int k = lane * 4; k < n; k += 256) {
+    const f32x4 v = Vec4<float>::load(src + k);
+    ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  ss = wave_sum(ss);
+  const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+  for (int k = lane * 4; k < n; k += 256) Vec4<T>::store(zn + (size_t)row * n + k, Vec4<float>::load(src + k) * inv);
+  if (lane == 0) inv_norm[row] = inv;
+}
+// dz = (dzn - zn (zn . dzn)) * inv_norm   (rows whose norm was clamped are not treated specially: ||z|| >= 1e-12 in practice)
+template <typename T>
+__global__ void __launch_bounds__(256) l2norm_rows_bwd_kernel(const float* __restrict__ dzn, const T* __restrict__ zn, const float* __restrict__ inv_norm,
+                                                               int M, int n, float* __restrict__ dz) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float dot = 0.f;
+  for (int k = lane * 4; k < n; k += 256) {
+    const f32x4 a = Vec4<float>::load(dzn + (size_t)row * n + k), b = Vec4<T>::load(zn + (size_t)row * n + k);
+    dot += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+  }
+  dot = wave_sum(dot);
+  const float inv = inv_norm[row];
+  for (int k = lane * 4; k < n; k += 256) {
+    const f32x4 a = Vec4<float>::load(dzn + (size_t)row * n + k), b = Vec4<T>::load(zn + (size_t)row * n + k);
+    Vec4<float>::store(dz + (size_t)row * n + k, (a - b * dot) * inv);
+  }
+}
+// torch.nn.utils.weight_norm (dim 0): W[k,:] = g[k] * v[k,:] / ||v[k,:]||
+template <typename T>
+__global__ void __launch_bounds__(256) weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g, int K, int n, T* __restrict__ w,
+                                                               float* __restrict__ inv_norm) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= K) return;
+  const float* src = v + (size_t)row * n;
+  float ss = 0.f;
+  for (int k = lane * 4; k < n; k += 256) {
+    const f32x4 x = Vec4<float>::load(src + k);
+    ss += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+  }
+  ss = wave_sum(ss);
+  const float inv = 1.0f / sqrtf(ss), sc = g[row] * inv;
+  for (int k = lane * 4; k < n; k += 256) Vec4<T>::store(w + (size_t)row * n + k, Vec4<float>::load(src + k) * sc);
+  if (lane == 0) inv_norm[row] = inv;
+}
+// dv = g / ||v|| * (dW - (dW . vhat) vhat),  dg = dW . vhat,  vhat = v / ||v||
+__global__ void __launch_bounds__(256) weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v, const float* __restrict__ g,
+                                                               const float* __restrict__ inv_norm, int K, int n, float* __restrict__ dv,
+                                                               float* __restrict__ dg) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= K) return;
+  const float inv = inv_norm[row];
+  float dot = 0.f;
+  for (int k = lane * 4; k < n; k += 256) {
+    const f32x4 a = Vec4<float>::load(dw + (size_t)row * n + k), b = Vec4<float>::load(v + (size_t)row * n + k) * inv;
+    dot += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+  }
+  dot = wave_sum(dot);
+  const float sc = g[row] * inv;
+  for (int k = lane * 4; k < n; k += 256) {
+    const f32x4 a = Vec4<float>::load(dw + (size_t)row * n + k), b = Vec4<float>::load(v + (size_t)row * n + k) * inv;
+    Vec4<float>::store(dv + (size_t)row * n + k, (a - b * dot) * sc);
+  }
+  if (dg && lane == 0) dg[row] = dot;
+}
+
 }  // namespace
 }  // namespace hct
 
@@ -174,6 +247,33 @@ int hct_dino_loss(const void* student, const void* teacher, int dtype, int V, in
   hipLaunchKernelGGL(dino_fold_kernel, dim3(1), dim3(256), 0, s, partial, B * nchunk, 1.0f / ((float)nterms * (float)B), loss);
   if (batch_center_sum) hipLaunchKernelGGL(dino_center_fold_kernel, dim3((K / 4 + 255) / 256), dim3(256), 0, s, cpart, B, K, batch_center_sum);
   HCT_CHECK_LAUNCH("hct_dino_loss");
+  return 0;
+}
+
+int hct_l2norm_rows_fwd(const float* z, int M, int n, void* zn, int zn_dtype, float* inv_norm, void* stream) {
+  HCT_REQUIRE(z && zn && inv_norm && M >= 0 && n > 0 && n % 4 == 0, "hct_l2norm_rows_fwd: bad arguments");
+  if (M == 0) return 0;
+  HCT_DISPATCH_DTYPE(zn_dtype, T, hipLaunchKernelGGL(l2norm_rows_fwd_kernel<T>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, M, n, (T*)zn, inv_norm));
+  HCT_CHECK_LAUNCH("hct_l2norm_rows_fwd");
+  return 0;
+}
+int hct_l2norm_rows_bwd(const float* dzn, const void* zn, int zn_dtype, const float* inv_norm, int M, int n, float* dz, void* stream) {
+  HCT_REQUIRE(dzn && zn && inv_norm && dz && M >= 0 && n > 0 && n % 4 == 0, "hct_l2norm_rows_bwd: bad arguments");
+  if (M == 0) return 0;
+  HCT_DISPATCH_DTYPE(zn_dtype, T, hipLaunchKernelGGL(l2norm_rows_bwd_kernel<T>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dzn, (const T*)zn, inv_norm, M, n, dz));
+  HCT_CHECK_LAUNCH("hct_l2norm_rows_bwd");
+  return 0;
+}
+int hct_weight_norm_fwd(const float* v, const float* g, int K, int n, void* w, int w_dtype, float* inv_norm, void* stream) {
+  HCT_REQUIRE(v && g && w && inv_norm && K > 0 && n > 0 && n % 4 == 0, "hct_weight_norm_fwd: bad arguments");
+  HCT_DISPATCH_DTYPE(w_dtype, T, hipLaunchKernelGGL(weight_norm_fwd_kernel<T>, dim3((K + 3) / 4), dim3(256), 0, (hipStream_t)stream, v, g, K, n, (T*)w, inv_norm));
+  HCT_CHECK_LAUNCH("hct_weight_norm_fwd");
+  return 0;
+}
+int hct_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* inv_norm, int K, int n, float* dv, float* dg, void* stream) {
+  HCT_REQUIRE(dw && v && g && inv_norm && dv && K > 0 && n > 0 && n % 4 == 0, "hct_weight_norm_bwd: bad arguments");
+  hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((K + 3) / 4), dim3(256), 0, (hipStream_t)stream, dw, v, g, inv_norm, K, n, dv, dg);
+  HCT_CHECK_LAUNCH("hct_weight_norm_bwd");
   return 0;
 }
 

@@ -54,7 +54,7 @@ __global__ void patch_gather_kernel(const TX* __restrict__ x, const int32_t* __r
   const int r = blockIdx.x;  // b*K + j
   const int b = r / K, j = r - b * K;
   const int g = S / P;
-  const int l = ids_shuffle[(size_t)b * L + j];
+  const int l = ids_shuffle ? ids_shuffle[(size_t)b * L + j] : j;  // NULL: every patch in grid order (plain ViT)
   const int gh = l / (g * g), gw = (l / g) % g, gd = l % g;
   const int P4 = P >> 2;
   const int nvec = C * P * P * P4;
@@ -124,6 +124,15 @@ __global__ void encoder_assemble_bwd_pos_kernel(const float* __restrict__ dh0, c
     }
     Vec4<float>::store(dpos + (size_t)l * D + d, acc);
   }
+}
+
+template <typename T>
+__global__ void vit_assemble_bwd_tok_kernel(const float* __restrict__ dh0, int L, int R, int D, T* __restrict__ dtok) {
+  const int r = blockIdx.x;  // b*L + l
+  const int b = r / L, l = r - b * L;
+  const float* src = dh0 + ((size_t)b * (1 + R + L) + 1 + R + l) * D;
+  T* out = dtok + (size_t)r * D;
+  for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) Vec4<T>::store(out + d, Vec4<float>::load(src + d));
 }
 
 // out[d] = sum_b src[b*stride + d]   (row 0 of each volume: cls-token gradients)
@@ -834,6 +843,25 @@ int hct_encoder_assemble_bwd(const float* dh0, const int32_t* ids_restore, int B
   if (dcls) hipLaunchKernelGGL(strided_rowsum_kernel, dim3((D + 255) / 256), dim3(256), 0, s, dh0, B, (size_t)(K + 1) * D, D, dcls);
   if (dpos) hipLaunchKernelGGL(encoder_assemble_bwd_pos_kernel, dim3(L), dim3(threads), 0, s, dh0, ids_restore, B, L, K, D, dpos);
   HCT_CHECK_LAUNCH("hct_encoder_assemble_bwd");
+  return 0;
+}
+
+// backward of hct_vit_assemble_fwd: dtok[b*L+l] = dh0[b, 1+R+l] (cast); dcls = sum_b dh0[b,0]; dreg[r] = sum_b dh0[b,1+r];
+// dpos[l] = sum_b dh0[b,1+R+l]  (sums in batch order)
+int hct_vit_assemble_bwd(const float* dh0, int B, int L, int R, int D, void* dtok, int dtok_dtype, float* dcls, float* dreg, float* dpos,
+                         void* stream) {
+  HCT_REQUIRE(dh0 && B > 0 && L > 0 && R >= 0 && D > 0 && D % 4 == 0, "hct_vit_assemble_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t stride = (size_t)(1 + R + L) * D;
+  if (dtok) {
+    HCT_DISPATCH_DTYPE(dtok_dtype, T, hipLaunchKernelGGL(hct::vit_assemble_bwd_tok_kernel<T>, dim3(B * L), dim3(D / 4 >= 256 ? 256 : 64), 0, s, dh0, L,
+                                                        R, D, (T*)dtok));
+  }
+  if (dcls) hipLaunchKernelGGL(strided_rowsum_kernel, dim3((D + 255) / 256), dim3(256), 0, s, dh0, B, stride, D, dcls);
+  // registers and position rows: the rows 1 .. R+L of every volume, summed over the batch -> one launch over (R + L) * D columns
+  if (dreg && R > 0) hipLaunchKernelGGL(strided_rowsum_kernel, dim3((R * D + 255) / 256), dim3(256), 0, s, dh0 + D, B, stride, R * D, dreg);
+  if (dpos) hipLaunchKernelGGL(strided_rowsum_kernel, dim3((L * D + 255) / 256), dim3(256), 0, s, dh0 + (size_t)(1 + R) * D, B, stride, L * D, dpos);
+  HCT_CHECK_LAUNCH("hct_vit_assemble_bwd");
   return 0;
 }
 

@@ -39,6 +39,10 @@ struct hct_mae_plan {
   std::map<std::string, int> pindex;
   int64_t param_elems = 0, bf16t_elems = 0;
   // parameter indices
+  bool vit = false;  // encoder-only plan (plain ViT backbone)
+  int R = 0;         // register tokens
+  float norm_eps = 1e-5f;
+  int p_reg = -1;
   int p_pe_w, p_pe_b, p_pos, p_cls, p_norm_w, p_norm_b, p_de_w, p_de_b, p_mask, p_dcls, p_dpos, p_dnorm_w, p_dnorm_b,
       p_pred_w, p_pred_b;
   std::vector<BlockP> enc, dec;
@@ -321,20 +325,27 @@ extern "C" {
 hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int compute_dtype) {
   if (!c || batch <= 0 || (compute_dtype != HCT_F32 && compute_dtype != HCT_BF16)) { set_error("hct_mae_plan_create: bad arguments"); return nullptr; }
   if (c->patch_size <= 0 || c->input_size % c->patch_size || c->patch_size % 4) { set_error("hct_mae_plan_create: input_size %% patch_size != 0 or patch_size %% 4 != 0"); return nullptr; }
-  if (c->encoder_embed_dim % c->encoder_num_heads || c->decoder_embed_dim % c->decoder_num_heads) { set_error("hidden size should be divisible by num_heads"); return nullptr; }
-  if (c->encoder_embed_dim % 4 || c->decoder_embed_dim % 4 || c->encoder_mlp_dim % 4 || c->decoder_mlp_dim % 4) { set_error("embed/mlp dims must be multiples of 4"); return nullptr; }
+  const bool enc_only = c->encoder_only != 0;
+  if (c->encoder_embed_dim % c->encoder_num_heads || (!enc_only && c->decoder_embed_dim % c->decoder_num_heads)) { set_error("hidden size should be divisible by num_heads"); return nullptr; }
+  if (c->encoder_embed_dim % 4 || c->encoder_mlp_dim % 4 || (!enc_only && (c->decoder_embed_dim % 4 || c->decoder_mlp_dim % 4))) { set_error("embed/mlp dims must be multiples of 4"); return nullptr; }
   hct_mae_plan* p = new hct_mae_plan();
   p->cfg = *c;
   p->B = batch; p->dt = compute_dtype;
   p->g = c->input_size / c->patch_size;
   p->L = p->g * p->g * p->g;
+  p->vit = c->encoder_only != 0;
+  p->R = p->vit ? c->num_register_tokens : 0;
+  p->norm_eps = (p->vit && c->final_norm_eps > 0.f) ? c->final_norm_eps : 1e-5f;
+  if (p->R < 0) { set_error("num_register_tokens < 0"); delete p; return nullptr; }
   p->K = (int)((double)p->L * (1.0 - c->mask_ratio));  // int(L * (1 - mask_ratio)) in double, as Python evaluates mae.py:205
+  if (p->vit) p->K = p->L;  // the plain ViT embeds every patch
   p->pd = c->in_chans * c->patch_size * c->patch_size * c->patch_size;
-  p->Ne = p->K + 1; p->Nd = p->L + 1;
+  p->Ne = p->K + 1 + p->R; p->Nd = p->vit ? 0 : p->L + 1;
   p->Me = batch * p->Ne; p->Md = batch * p->Nd;
-  p->D = c->encoder_embed_dim; p->Dd = c->decoder_embed_dim;
-  p->Mlp = c->encoder_mlp_dim; p->Mlpd = c->decoder_mlp_dim;
-  p->H = c->encoder_num_heads; p->Hd = c->decoder_num_heads;
+  if (p->vit) p->cfg.decoder_depth = 0;  // no decoder: its loops below run zero times, its buffers have zero rows
+  p->D = c->encoder_embed_dim; p->Dd = p->vit ? c->encoder_embed_dim : c->decoder_embed_dim;
+  p->Mlp = c->encoder_mlp_dim; p->Mlpd = p->vit ? c->encoder_mlp_dim : c->decoder_mlp_dim;
+  p->H = c->encoder_num_heads; p->Hd = p->vit ? c->encoder_num_heads : c->decoder_num_heads;
   if (p->K < 1) { set_error("mask_ratio leaves no visible patches"); delete p; return nullptr; }
   const bool ub = c->use_bias != 0;
   const int P = c->patch_size, C = c->in_chans;
@@ -345,6 +356,7 @@ hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int comput
   p->p_pe_b = add_param(p, "patch_embedding.patch_embeddings.bias", {p->D}, true, false, false);
   p->p_pos = c->pos_embed ? add_param(p, "patch_embedding.position_embeddings", {1, p->L, p->D}, true, false, false) : -1;
   p->p_cls = add_param(p, "cls_token", {1, 1, p->D}, true, false, false);
+  if (p->R > 0) p->p_reg = add_param(p, "register_tokens", {1, p->R, p->D}, true, false, false);
   seg.push_back({g0, p->param_elems});
   for (int i = 0; i < c->encoder_depth; ++i) {
     g0 = p->param_elems;
@@ -354,13 +366,17 @@ hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int comput
   g0 = p->param_elems;
   p->p_norm_w = add_param(p, "norm.weight", {p->D}, true, false, false);
   p->p_norm_b = add_param(p, "norm.bias", {p->D}, true, false, false);
+  if (p->vit) {
+    seg.push_back({g0, p->param_elems});
+    p->p_de_w = p->p_de_b = p->p_mask = p->p_dcls = p->p_dpos = p->p_dnorm_w = p->p_dnorm_b = p->p_pred_w = p->p_pred_b = -1;
+  } else {
   p->p_de_w = add_param(p, "decoder_embed.weight", {p->Dd, p->D}, true, true, true);
   p->p_de_b = ub ? add_param(p, "decoder_embed.bias", {p->Dd}, true, false, false) : -1;
   p->p_mask = add_param(p, "mask_token", {1, 1, p->Dd}, true, false, false);
   p->p_dcls = add_param(p, "decoder_cls_token", {1, 1, p->Dd}, true, false, false);
   p->p_dpos = add_param(p, "decoder_pos_embed", {1, p->L, p->Dd}, false, false, false);  // mae.py:92 frozen
   seg.push_back({g0, p->param_elems});
-  for (int i = 0; i < c->decoder_depth; ++i) {
+  for (int i = 0; i < p->cfg.decoder_depth; ++i) {
     g0 = p->param_elems;
     p->dec.push_back(add_block(p, "decoder_blocks." + std::to_string(i), p->Dd, p->Mlpd, ub));
     seg.push_back({g0, p->param_elems});
@@ -371,6 +387,7 @@ hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int comput
   p->p_pred_w = add_param(p, "decoder_pred.weight", {p->pd, p->Dd}, true, true, true);
   p->p_pred_b = ub ? add_param(p, "decoder_pred.bias", {p->pd}, true, false, false) : -1;
   seg.push_back({g0, p->param_elems});
+  }
   // backward stages complete the groups in reverse
   for (int i = (int)seg.size() - 1; i >= 0; --i) p->stage_range.push_back(seg[i]);
 
@@ -390,8 +407,8 @@ hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int comput
   p->a_lat_mean = w.take(Me * 4);
   p->a_lat_rstd = w.take(Me * 4);
   p->a_e = w.take(Me * Dd * es);
-  for (int i = 0; i <= c->decoder_depth; ++i) p->h_dec.push_back(w.take(Md * Dd * 4));
-  for (int i = 0; i < c->decoder_depth; ++i) p->adec.push_back(alloc_block(w, Md, Dd, p->Mlpd, (size_t)batch * p->Hd * p->Nd, es));
+  for (int i = 0; i <= p->cfg.decoder_depth; ++i) p->h_dec.push_back(w.take(Md * Dd * 4));
+  for (int i = 0; i < p->cfg.decoder_depth; ++i) p->adec.push_back(alloc_block(w, Md, Dd, p->Mlpd, (size_t)batch * p->Hd * p->Nd, es));
   p->a_ynorm = w.take(Md * Dd * es);
   p->a_yn_mean = w.take(Md * 4);
   p->a_yn_rstd = w.take(Md * 4);
@@ -439,7 +456,7 @@ hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int comput
   for (int i = 0; i < c->encoder_depth; ++i) reg("enc" + std::to_string(i) + ".out", p->h_enc[i + 1], p->Me, p->D, HCT_F32);
   reg("latent", p->a_latent, p->Me, p->D, p->dt);
   reg("dec_in", p->h_dec[0], p->Md, p->Dd, HCT_F32);
-  for (int i = 0; i < c->decoder_depth; ++i) reg("dec" + std::to_string(i) + ".out", p->h_dec[i + 1], p->Md, p->Dd, HCT_F32);
+  for (int i = 0; i < p->cfg.decoder_depth; ++i) reg("dec" + std::to_string(i) + ".out", p->h_dec[i + 1], p->Md, p->Dd, HCT_F32);
   reg("pred_full", p->a_pred, p->Md, p->pd, p->dt);
   reg("dpred_full", p->a_dpred, p->Md, p->pd, p->dt);
   if (c->encoder_depth > 0) {
@@ -501,6 +518,7 @@ int hct_mae_refresh_weights(hct_mae_plan* p, int with_plain, void* stream) {
 
 int hct_mae_forward(hct_mae_plan* p, const void* x, int x_dtype, const float* noise, float* loss, float grad_scale, void* stream) {
   HCT_REQUIRE(p && p->ws && x && noise && loss, "hct_mae_forward: plan not bound or null argument");
+  HCT_REQUIRE(!p->vit, "hct_mae_forward: encoder-only plans are driven by hct_vit_forward");
   HCT_REQUIRE(x_dtype == HCT_F32 || x_dtype == HCT_F16, "hct_mae_forward: volumes are fp32 or fp16");
   hipStream_t s = (hipStream_t)stream;
   unsigned char* ws = p->ws;
@@ -535,6 +553,56 @@ int hct_mae_forward(hct_mae_plan* p, const void* x, int x_dtype, const float* no
   p->fwd_done = true;
   p->dpred_done = train;
   return 0;
+}
+
+int hct_vit_forward(hct_mae_plan* p, const void* x, int x_dtype, void* stream) {
+  HCT_REQUIRE(p && p->ws && x, "hct_vit_forward: plan not bound or null argument");
+  HCT_REQUIRE(p->vit, "hct_vit_forward: the plan was not created with encoder_only = 1");
+  HCT_REQUIRE(x_dtype == HCT_F32 || x_dtype == HCT_F16, "hct_vit_forward: volumes are fp32 or fp16");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned char* ws = p->ws;
+  const hct_mae_config& c = p->cfg;
+  const int B = p->B;
+  // PatchEmbeddingBlock on every patch (patch_embedding.py:149-156), class token and register tokens (vit.py:147-160)
+  RC(hct_patch_gather(x, x_dtype, nullptr, B, c.in_chans, c.input_size, c.patch_size, p->L, p->L, ws + p->a_patches, p->dt, s));
+  RC(linear_fwd(p, ws + p->a_patches, B * p->L, p->pd, p->p_pe_w, p->p_pe_b, p->D, ws + p->a_tok, p->dt, HCT_ACT_NONE, nullptr, nullptr, s));
+  RC(hct_vit_assemble_fwd(ws + p->a_tok, p->dt, p->pf(p->p_cls), p->p_reg >= 0 ? p->pf(p->p_reg) : nullptr, p->p_pos >= 0 ? p->pf(p->p_pos) : nullptr, B,
+                          p->L, p->R, p->D, (float*)(ws + p->h_enc[0]), s));
+  for (int i = 0; i < c.encoder_depth; ++i)
+    RC(block_forward(p, p->enc[i], p->aenc[i], (const float*)(ws + p->h_enc[i]), (float*)(ws + p->h_enc[i + 1]), B, p->Ne, p->D, p->Mlp, p->H, s));
+  RC(hct_layernorm_fwd((const float*)(ws + p->h_enc[c.encoder_depth]), p->pf(p->p_norm_w), p->pf(p->p_norm_b), p->Me, p->D, p->norm_eps,
+                       ws + p->a_latent, p->dt, (float*)(ws + p->a_lat_mean), (float*)(ws + p->a_lat_rstd), s));
+  p->fwd_done = true;
+  return 0;
+}
+
+int hct_vit_backward_stage(hct_mae_plan* p, int stage, const void* dlatent, void* stream) {
+  HCT_REQUIRE(p && p->ws && p->grads && p->vit, "hct_vit_backward_stage: plan not bound, no gradient buffer, or not an encoder-only plan");
+  if (!p->fwd_done) { set_error("hct_vit_backward_stage: forward has not run"); return HCT_E_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  unsigned char* ws = p->ws;
+  const int B = p->B, ne = p->cfg.encoder_depth;
+  float* dh = (float*)(ws + p->s_dh);
+  void* dhs = ws + p->s_dh_shadow;
+  void* small = ws + p->s_small;
+  if (stage == 0) {  // final norm
+    HCT_REQUIRE(dlatent, "hct_vit_backward_stage: stage 0 needs dlatent");
+    return hct_layernorm_bwd(dlatent, p->dt, (const float*)(ws + p->h_enc[ne]), (const float*)(ws + p->a_lat_mean), (const float*)(ws + p->a_lat_rstd),
+                             p->pf(p->p_norm_w), nullptr, p->Me, p->D, dh, dhs, p->dt, p->gf(p->p_norm_w), p->gf(p->p_norm_b),
+                             ne > 0 ? p->gf(p->enc[ne - 1].fc2_b) : nullptr, small, p->s_small_bytes, s);
+  }
+  if (stage <= ne) {
+    const int i = ne - stage;
+    return block_backward(p, p->enc[i], p->aenc[i], (const float*)(ws + p->h_enc[i]), B, p->Ne, p->D, p->Mlp, p->H, i > 0 ? p->enc[i - 1].fc2_b : -1, s);
+  }
+  if (stage == ne + 1) {  // input assembly -> patch embedding
+    void* dtok = ws + p->s_do;
+    RC(hct_vit_assemble_bwd(dh, B, p->L, p->R, p->D, dtok, p->dt, p->gf(p->p_cls), p->p_reg >= 0 ? p->gf(p->p_reg) : nullptr,
+                            p->p_pos >= 0 ? p->gf(p->p_pos) : nullptr, s));
+    return linear_wgrad(p, dtok, ws + p->a_patches, B * p->L, p->D, p->pd, p->p_pe_w, p->p_pe_b, s);
+  }
+  set_error("hct_vit_backward_stage: stage %d out of range", stage);
+  return HCT_E_BADARG;
 }
 
 int hct_mae_set_loss_grad(hct_mae_plan* p, const float* dloss) {

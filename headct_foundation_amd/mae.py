@@ -162,76 +162,14 @@ class _MAEFunction(torch.autograd.Function):
         return None, None, None, None, None
 
 
-class MaskedAutoencoderViT(nn.Module):
-    """Masked Autoencoder with VisionTransformer backbone (HIP / gfx950 implementation)."""
+class FlatPlanModule(nn.Module):
+    """Host side shared by the plan-driven models (MAE, ViT backbone): every Parameter is a view into ONE flat fp32 buffer laid
+    out by the native plan, gradients live in a second flat buffer that the staged native backward fills from its end to its
+    start (= gradient-bucket order for the data-parallel all-reduce), bf16 working copies are refreshed when the masters change.
+    Subclasses register their parameters under the reference's names, fill `self._ccfg` / `self._dt`, then call
+    `_init_flat_state()` and `_build_flat(cpu)`."""
 
-    def __init__(self, input_size: int, patch_size: int, mask_ratio: float, in_chans: int = 1, dropout_rate: float = 0.,
-                 spatial_dims: int = 3, patch_embed: str = 'conv', pos_embed: str = 'learnable', encoder_depth: int = 12,
-                 encoder_embed_dim: int = 768, encoder_mlp_dim: int = 3072, encoder_num_heads: int = 12,
-                 decoder_depth: int = 8, decoder_embed_dim: int = 768, decoder_mlp_dim: int = 3072,
-                 decoder_num_heads: int = 16, norm_pix_loss: bool = False, use_bias: bool = False,
-                 norm_layer=nn.LayerNorm, compute_dtype: str = "bf16"):
-        super().__init__()
-        input_size, patch_size = _to_3tuple(input_size), _to_3tuple(patch_size)
-        if spatial_dims != 3 or len(set(input_size)) != 1 or len(set(patch_size)) != 1:
-            raise HctError("the HIP MAE path supports cubic 3-D volumes and patches")
-        if patch_embed != "conv":
-            raise ValueError(f"patch_embed type {patch_embed} not supported.")
-        if pos_embed not in _POS:
-            raise ValueError(f"pos_embed type {pos_embed} not supported.")
-        if not (0 <= dropout_rate <= 1):
-            raise ValueError("dropout_rate should be between 0 and 1.")
-        if dropout_rate != 0.0:
-            raise HctError("dropout_rate != 0 is outside the HIP hot path (the reference MAE yaml uses 0.)")
-        if norm_layer is not nn.LayerNorm:
-            raise HctError("only nn.LayerNorm is supported on the HIP hot path (MAE.NORM_LAYER: layernorm)")
-        if encoder_embed_dim % encoder_num_heads or decoder_embed_dim % decoder_num_heads:
-            raise ValueError("hidden_size should be divisible by num_heads.")
-        for m, p in zip(input_size, patch_size):
-            if m < p:
-                raise ValueError("patch_size should be smaller than img_size.")
-            assert m % p == 0, "input size and patch size are not proper"
-        if compute_dtype not in ("bf16", "fp32"):
-            raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
-
-        self.input_size, self.patch_size = input_size, patch_size
-        self.mask_ratio, self.spatial_dims, self.pos_embed, self.norm_pix_loss = mask_ratio, spatial_dims, pos_embed, norm_pix_loss
-        self.encoder_embed_dim, self.decoder_embed_dim = encoder_embed_dim, decoder_embed_dim
-        self.in_chans = in_chans
-        self.out_chans = in_chans * int(np.prod(patch_size))
-        self.grid_size = [i // p for i, p in zip(input_size, patch_size)]
-        self.compute_dtype = compute_dtype
-        num_patches = int(np.prod(self.grid_size))
-        self.num_patches = num_patches
-        D, Dd, P = encoder_embed_dim, decoder_embed_dim, patch_size[0]
-
-        # ---- parameters: the reference's names and registration order (mae.py:90-121) ----
-        self.cls_token = nn.Parameter(torch.zeros(1, 1, D))
-        self.decoder_cls_token = nn.Parameter(torch.zeros(1, 1, Dd))
-        self.decoder_pos_embed = nn.Parameter(torch.zeros(1, num_patches, Dd), requires_grad=False)
-        self.patch_embedding = _Holder()
-        self.patch_embedding.n_patches = num_patches  # attribute interpolate_pos_embed reads (patch_embedding.py:96)
-        if pos_embed != "none":
-            self.patch_embedding.position_embeddings = nn.Parameter(torch.zeros(1, num_patches, D))
-        else:
-            self.patch_embedding.position_embeddings = None
-        self.patch_embedding.patch_embeddings = _Affine(D, in_chans, P, P, P, bias_shape=(D,))
-        self.blocks = nn.ModuleList([_block(D, encoder_mlp_dim, use_bias) for _ in range(encoder_depth)])
-        self.decoder_blocks = nn.ModuleList([_block(Dd, decoder_mlp_dim, use_bias) for _ in range(decoder_depth)])
-        self.norm = _Affine(D, bias_shape=(D,))
-        self.decoder_norm = _Affine(Dd, bias_shape=(Dd,))
-        self.decoder_embed = _Affine(Dd, D, bias_shape=(Dd,) if use_bias else None)
-        self.decoder_pred = _Affine(P ** 3 * in_chans, Dd, bias_shape=(P ** 3 * in_chans,) if use_bias else None)
-        self.mask_token = nn.Parameter(torch.zeros(1, 1, Dd))
-
-        self._ccfg = _lib.MaeConfig(
-            input_size=input_size[0], patch_size=P, in_chans=in_chans, mask_ratio=float(mask_ratio), pos_embed=_POS[pos_embed],
-            encoder_depth=encoder_depth, encoder_embed_dim=D, encoder_mlp_dim=encoder_mlp_dim, encoder_num_heads=encoder_num_heads,
-            decoder_depth=decoder_depth, decoder_embed_dim=Dd, decoder_mlp_dim=decoder_mlp_dim, decoder_num_heads=decoder_num_heads,
-            norm_pix_loss=int(bool(norm_pix_loss)), use_bias=int(bool(use_bias)))
-        self._dt = HCT_BF16 if compute_dtype == "bf16" else HCT_F32
-        self.len_keep = int(num_patches * (1 - mask_ratio))  # mae.py:205
-
+    def _init_flat_state(self) -> None:
         self._plans: Dict[int, _Plan] = {}
         self._weights_version = 0      # bumped whenever fp32 master weights may have changed
         self._shadow_version = -1      # version the bf16 working copies correspond to
@@ -242,42 +180,6 @@ class MaskedAutoencoderViT(nn.Module):
         self._managed_updates = False  # True once a HipAdamW owns the weight updates
         self._plain_fresh = False
         self._layout: List[Tuple[str, int, int, Tuple[int, ...], bool, int]] = []
-        self.initialize_weights()
-        self._build_flat(torch.device("cpu"))
-
-    # ------------------------------------------------------------------------------------------
-    # initialisation (mae.py:125-148; patch_embedding.py:107-124; Conv3d keeps torch's default)
-    # ------------------------------------------------------------------------------------------
-    def initialize_weights(self) -> None:
-        D, Dd = self.encoder_embed_dim, self.decoder_embed_dim
-        pe = self.patch_embedding
-        with torch.no_grad():
-            conv = pe.patch_embeddings
-            nn.init.kaiming_uniform_(conv.weight, a=math.sqrt(5))  # torch Conv3d.reset_parameters
-            fan_in = conv.weight[0].numel()
-            bound = 1 / math.sqrt(fan_in)
-            nn.init.uniform_(conv.bias, -bound, bound)
-            if self.pos_embed == "learnable":
-                nn.init.trunc_normal_(pe.position_embeddings, mean=0.0, std=0.02, a=-2.0, b=2.0)
-            elif self.pos_embed == "sincos":
-                pe.position_embeddings.copy_(build_sincos_position_embedding(self.grid_size, D, 3))
-            if self.pos_embed == "sincos":
-                self.decoder_pos_embed.copy_(build_sincos_position_embedding(self.grid_size, Dd, 3))
-            else:
-                nn.init.trunc_normal_(self.decoder_pos_embed, std=.02)
-            nn.init.trunc_normal_(self.cls_token, std=.02)
-            nn.init.trunc_normal_(self.decoder_cls_token, std=.02)
-            nn.init.trunc_normal_(self.mask_token, std=.02)
-            for name, m in self.named_modules():
-                if not isinstance(m, _Affine) or m is conv:
-                    continue
-                if m.weight.dim() == 2:  # nn.Linear: xavier_uniform weight, zero bias (mae.py:143-146)
-                    nn.init.xavier_uniform_(m.weight)
-                    if m.bias is not None:
-                        nn.init.constant_(m.bias, 0)
-                else:  # nn.LayerNorm (mae.py:147-148)
-                    nn.init.constant_(m.bias, 0)
-                    nn.init.constant_(m.weight, 1.0)
 
     # ------------------------------------------------------------------------------------------
     # flat storage: every Parameter is a view into one fp32 buffer laid out by the native plan
@@ -360,7 +262,7 @@ class MaskedAutoencoderViT(nn.Module):
     # ------------------------------------------------------------------------------------------
     def _plan_for(self, batch: int) -> _Plan:
         if not self._flat.is_cuda:
-            raise HctError("MaskedAutoencoderViT (HIP) needs its parameters on a GPU: call .to('cuda') first; "
+            raise HctError(f"{type(self).__name__} (HIP) needs its parameters on a GPU: call .to('cuda') first; "
                            "there is no CPU fallback for this path")
         plan = self._plans.get(batch)
         if plan is None:
@@ -401,8 +303,16 @@ class MaskedAutoencoderViT(nn.Module):
         return accumulate
 
     def _run_backward(self, plan: _Plan, x: torch.Tensor, grad_out: torch.Tensor) -> None:
+        """MAE: the staged native backward seeded by the (device) scalar dLoss."""
         lib = plan.lib
+        g = grad_out.detach().to(dtype=torch.float32).reshape(1).contiguous()
+        _lib.check(lib.hct_mae_set_loss_grad(plan.handle, g.data_ptr()), "hct_mae_set_loss_grad")
+        self._keep_alive = g
         st = _lib.stream_ptr()
+        self._run_staged_backward(plan, lambda s: lib.hct_mae_backward_stage(plan.handle, s, st), "hct_mae_backward_stage")
+
+    def _run_staged_backward(self, plan: _Plan, stage_call, what: str) -> None:
+        lib = plan.lib
         # a second backward without zero_grad() adds to what is there (torch semantics).  The native stages overwrite the
         # flat buffer, so the earlier gradient is parked and added back at the end -- AFTER the data-parallel reduction of
         # the fresh gradient (every backward is reduced, as torch's DDP does; the parked part is already the mean).
@@ -410,15 +320,11 @@ class MaskedAutoencoderViT(nn.Module):
         if not self._grad_overwrite and any(p.grad is not None for p in self.parameters()):
             self._attach_grads()  # a foreign / preset .grad tensor is folded into the flat buffer first
             parked = self._flat_grad.clone()
-        # the data-parallel mean (1 / world) is already folded into the seed the forward wrote (ddp.py sets _grad_prescale)
-        g = grad_out.detach().to(dtype=torch.float32).reshape(1).contiguous()
-        _lib.check(lib.hct_mae_set_loss_grad(plan.handle, g.data_ptr()), "hct_mae_set_loss_grad")
         for s in range(plan.nstages):
-            _lib.check(lib.hct_mae_backward_stage(plan.handle, s, st), f"hct_mae_backward_stage({s})")
+            _lib.check(stage_call(s), f"{what}({s})")
             if self._bucket_hook is not None:
                 b, e = plan.stage_ranges[s]
                 self._bucket_hook(s, b, e)
-        self._keep_alive = g
         if self._post_backward_hook is not None:
             self._post_backward_hook()  # data parallel: the compute stream now waits for the collectives
         if parked is not None:
@@ -429,6 +335,115 @@ class MaskedAutoencoderViT(nn.Module):
     def zero_grad(self, set_to_none: bool = True) -> None:
         super().zero_grad(set_to_none=set_to_none)
         self._grad_overwrite = True
+
+
+class MaskedAutoencoderViT(FlatPlanModule):
+    """Masked Autoencoder with VisionTransformer backbone (HIP / gfx950 implementation)."""
+
+    def __init__(self, input_size: int, patch_size: int, mask_ratio: float, in_chans: int = 1, dropout_rate: float = 0.,
+                 spatial_dims: int = 3, patch_embed: str = 'conv', pos_embed: str = 'learnable', encoder_depth: int = 12,
+                 encoder_embed_dim: int = 768, encoder_mlp_dim: int = 3072, encoder_num_heads: int = 12,
+                 decoder_depth: int = 8, decoder_embed_dim: int = 768, decoder_mlp_dim: int = 3072,
+                 decoder_num_heads: int = 16, norm_pix_loss: bool = False, use_bias: bool = False,
+                 norm_layer=nn.LayerNorm, compute_dtype: str = "bf16"):
+        super().__init__()
+        input_size, patch_size = _to_3tuple(input_size), _to_3tuple(patch_size)
+        if spatial_dims != 3 or len(set(input_size)) != 1 or len(set(patch_size)) != 1:
+            raise HctError("the HIP MAE path supports cubic 3-D volumes and patches")
+        if patch_embed != "conv":
+            raise ValueError(f"patch_embed type {patch_embed} not supported.")
+        if pos_embed not in _POS:
+            raise ValueError(f"pos_embed type {pos_embed} not supported.")
+        if not (0 <= dropout_rate <= 1):
+            raise ValueError("dropout_rate should be between 0 and 1.")
+        if dropout_rate != 0.0:
+            raise HctError("dropout_rate != 0 is outside the HIP hot path (the reference MAE yaml uses 0.)")
+        if norm_layer is not nn.LayerNorm:
+            raise HctError("only nn.LayerNorm is supported on the HIP hot path (MAE.NORM_LAYER: layernorm)")
+        if encoder_embed_dim % encoder_num_heads or decoder_embed_dim % decoder_num_heads:
+            raise ValueError("hidden_size should be divisible by num_heads.")
+        for m, p in zip(input_size, patch_size):
+            if m < p:
+                raise ValueError("patch_size should be smaller than img_size.")
+            assert m % p == 0, "input size and patch size are not proper"
+        if compute_dtype not in ("bf16", "fp32"):
+            raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
+
+        self.input_size, self.patch_size = input_size, patch_size
+        self.mask_ratio, self.spatial_dims, self.pos_embed, self.norm_pix_loss = mask_ratio, spatial_dims, pos_embed, norm_pix_loss
+        self.encoder_embed_dim, self.decoder_embed_dim = encoder_embed_dim, decoder_embed_dim
+        self.in_chans = in_chans
+        self.out_chans = in_chans * int(np.prod(patch_size))
+        self.grid_size = [i // p for i, p in zip(input_size, patch_size)]
+        self.compute_dtype = compute_dtype
+        num_patches = int(np.prod(self.grid_size))
+        self.num_patches = num_patches
+        D, Dd, P = encoder_embed_dim, decoder_embed_dim, patch_size[0]
+
+        # ---- parameters: the reference's names and registration order (mae.py:90-121) ----
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, D))
+        self.decoder_cls_token = nn.Parameter(torch.zeros(1, 1, Dd))
+        self.decoder_pos_embed = nn.Parameter(torch.zeros(1, num_patches, Dd), requires_grad=False)
+        self.patch_embedding = _Holder()
+        self.patch_embedding.n_patches = num_patches  # attribute interpolate_pos_embed reads (patch_embedding.py:96)
+        if pos_embed != "none":
+            self.patch_embedding.position_embeddings = nn.Parameter(torch.zeros(1, num_patches, D))
+        else:
+            self.patch_embedding.position_embeddings = None
+        self.patch_embedding.patch_embeddings = _Affine(D, in_chans, P, P, P, bias_shape=(D,))
+        self.blocks = nn.ModuleList([_block(D, encoder_mlp_dim, use_bias) for _ in range(encoder_depth)])
+        self.decoder_blocks = nn.ModuleList([_block(Dd, decoder_mlp_dim, use_bias) for _ in range(decoder_depth)])
+        self.norm = _Affine(D, bias_shape=(D,))
+        self.decoder_norm = _Affine(Dd, bias_shape=(Dd,))
+        self.decoder_embed = _Affine(Dd, D, bias_shape=(Dd,) if use_bias else None)
+        self.decoder_pred = _Affine(P ** 3 * in_chans, Dd, bias_shape=(P ** 3 * in_chans,) if use_bias else None)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, Dd))
+
+        self._ccfg = _lib.MaeConfig(
+            input_size=input_size[0], patch_size=P, in_chans=in_chans, mask_ratio=float(mask_ratio), pos_embed=_POS[pos_embed],
+            encoder_depth=encoder_depth, encoder_embed_dim=D, encoder_mlp_dim=encoder_mlp_dim, encoder_num_heads=encoder_num_heads,
+            decoder_depth=decoder_depth, decoder_embed_dim=Dd, decoder_mlp_dim=decoder_mlp_dim, decoder_num_heads=decoder_num_heads,
+            norm_pix_loss=int(bool(norm_pix_loss)), use_bias=int(bool(use_bias)))
+        self._dt = HCT_BF16 if compute_dtype == "bf16" else HCT_F32
+        self.len_keep = int(num_patches * (1 - mask_ratio))  # mae.py:205
+
+        self._init_flat_state()
+        self.initialize_weights()
+        self._build_flat(torch.device("cpu"))
+
+    # ------------------------------------------------------------------------------------------
+    # initialisation (mae.py:125-148; patch_embedding.py:107-124; Conv3d keeps torch's default)
+    # ------------------------------------------------------------------------------------------
+    def initialize_weights(self) -> None:
+        D, Dd = self.encoder_embed_dim, self.decoder_embed_dim
+        pe = self.patch_embedding
+        with torch.no_grad():
+            conv = pe.patch_embeddings
+            nn.init.kaiming_uniform_(conv.weight, a=math.sqrt(5))  # torch Conv3d.reset_parameters
+            fan_in = conv.weight[0].numel()
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(conv.bias, -bound, bound)
+            if self.pos_embed == "learnable":
+                nn.init.trunc_normal_(pe.position_embeddings, mean=0.0, std=0.02, a=-2.0, b=2.0)
+            elif self.pos_embed == "sincos":
+                pe.position_embeddings.copy_(build_sincos_position_embedding(self.grid_size, D, 3))
+            if self.pos_embed == "sincos":
+                self.decoder_pos_embed.copy_(build_sincos_position_embedding(self.grid_size, Dd, 3))
+            else:
+                nn.init.trunc_normal_(self.decoder_pos_embed, std=.02)
+            nn.init.trunc_normal_(self.cls_token, std=.02)
+            nn.init.trunc_normal_(self.decoder_cls_token, std=.02)
+            nn.init.trunc_normal_(self.mask_token, std=.02)
+            for name, m in self.named_modules():
+                if not isinstance(m, _Affine) or m is conv:
+                    continue
+                if m.weight.dim() == 2:  # nn.Linear: xavier_uniform weight, zero bias (mae.py:143-146)
+                    nn.init.xavier_uniform_(m.weight)
+                    if m.bias is not None:
+                        nn.init.constant_(m.bias, 0)
+                else:  # nn.LayerNorm (mae.py:147-148)
+                    nn.init.constant_(m.bias, 0)
+                    nn.init.constant_(m.weight, 1.0)
 
     # ------------------------------------------------------------------------------------------
     # public API (reference: mae.py:150-192, 303-317)

@@ -16,12 +16,17 @@ import torch
 
 from . import _lib
 from ._lib import HctError
-from .mae import MaskedAutoencoderViT
+from .mae import FlatPlanModule, MaskedAutoencoderViT  # noqa: F401 (MaskedAutoencoderViT re-exported for callers)
+
+
+def _is_flat(m) -> bool:
+    """A model whose parameters / gradients live in flat fp32 buffers laid out in 1024-element units (MAE, ViT backbone, DINO head)."""
+    return isinstance(m, FlatPlanModule) or all(hasattr(m, a) for a in ("_flat", "_flat_grad", "_layout", "flat_segments"))
 
 
 def unwrap(model):
     """Strip DistributedDataParallel-style wrappers (`.module`)."""
-    while hasattr(model, "module") and not isinstance(model, MaskedAutoencoderViT):
+    while hasattr(model, "module") and not _is_flat(model):
         model = model.module
     return model
 
@@ -29,7 +34,7 @@ def unwrap(model):
 class _FlatState:
     """Device-side bookkeeping shared by clip and AdamW for one model."""
 
-    def __init__(self, model: MaskedAutoencoderViT):
+    def __init__(self, model):
         self.model = model
         self.flat_id = None
         self.refresh()
@@ -56,7 +61,7 @@ class _FlatState:
             self.refresh()
 
 
-def _state_for(model: MaskedAutoencoderViT) -> _FlatState:
+def _state_for(model) -> _FlatState:
     st = getattr(model, "_flat_state", None)
     if st is None:
         st = _FlatState(model)
@@ -75,8 +80,8 @@ def clip_gradients(model, clip: float, defer_to_optimizer: Optional[bool] = None
     gradients are scaled in place right here.
     """
     m = unwrap(model)
-    if not isinstance(m, MaskedAutoencoderViT):
-        raise HctError("clip_gradients (HIP) expects the HIP MaskedAutoencoderViT")
+    if not _is_flat(m):
+        raise HctError("clip_gradients (HIP) expects a flat-buffer HIP model (MaskedAutoencoderViT, ViTBackbone, DINOHead)")
     if not m._flat.is_cuda:
         raise HctError("clip_gradients (HIP) needs the model on a GPU; there is no CPU fallback")
     st = _state_for(m)
@@ -103,8 +108,8 @@ class HipAdamW(torch.optim.Optimizer):
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         m = unwrap(model)
-        if not isinstance(m, MaskedAutoencoderViT):
-            raise HctError("HipAdamW expects the HIP MaskedAutoencoderViT")
+        if not _is_flat(m):
+            raise HctError("HipAdamW expects a flat-buffer HIP model (MaskedAutoencoderViT, ViTBackbone, DINOHead)")
         self._model = m
         params = list(m.parameters())  # registration order == torch.optim.AdamW(model.parameters()) order
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,

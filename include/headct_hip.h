@@ -231,6 +231,13 @@ int hct_dino_loss(const void* student, const void* teacher, int dtype, int n_cro
                   size_t workspace_bytes, void* stream);
 int hct_dino_center_update(float* center, const float* batch_center_sum, int K, double momentum, double count, void* stream);
 int hct_ema_update(float* momentum_params, const float* params, int64_t n, double m, void* stream);
+/* DINOHead tail (src/models/dino_head.py:37-41): rows L2-normalised (F.normalize, eps 1e-12), prototype weights weight-normalised
+ * (torch.nn.utils.weight_norm, dim 0: W[k,:] = g[k] v[k,:] / ||v[k,:]||); forward keeps 1 / norm per row for the backward. */
+int hct_l2norm_rows_fwd(const float* z, int M, int n, void* zn, int zn_dtype, float* inv_norm, void* stream);
+int hct_l2norm_rows_bwd(const float* dzn, const void* zn, int zn_dtype, const float* inv_norm, int M, int n, float* dz, void* stream);
+int hct_weight_norm_fwd(const float* v, const float* g, int K, int n, void* w, int w_dtype, float* inv_norm, void* stream);
+int hct_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* inv_norm, int K, int n, float* dv, float* dg /* or NULL */,
+                        void* stream);
 
 /* HU windowing of loading_transforms (src/data/transforms.py:108-133): ScaleIntensityRanged(a_min, a_max, 0, 1, clip) for one
  * channel (window 40 +- 150), MultipleWindowScaleStack (transforms.py:8-36) for three ((40,80), (80,200), (600,2800) as
@@ -286,6 +293,12 @@ typedef struct hct_mae_config {
   int encoder_depth, encoder_embed_dim, encoder_mlp_dim, encoder_num_heads;
   int decoder_depth, decoder_embed_dim, decoder_mlp_dim, decoder_num_heads;
   int norm_pix_loss, use_bias;
+  /* encoder_only = 1 turns the plan into the plain ViT backbone of DINO pre-training (src/models/vit.py:144-173): every patch is
+   * embedded (no masking, mask_ratio ignored), class token, num_register_tokens register tokens behind it, encoder blocks, final
+   * LayerNorm with final_norm_eps (vit.py:124: 1e-6; 0 = the MAE default 1e-5); no decoder.  Driven by hct_vit_forward /
+   * hct_vit_backward_stage instead of hct_mae_forward / hct_mae_backward_stage. */
+  int encoder_only, num_register_tokens;
+  float final_norm_eps;
 } hct_mae_config;
 
 typedef struct hct_mae_plan hct_mae_plan;
@@ -330,6 +343,15 @@ int hct_mae_set_loss_grad(hct_mae_plan*, const float* dloss);
 int hct_mae_num_backward_stages(const hct_mae_plan*);
 int hct_mae_backward_stage_range(const hct_mae_plan*, int stage, int64_t* begin, int64_t* end);
 int hct_mae_backward_stage(hct_mae_plan*, int stage, void* stream);
+/* Plain ViT backbone (plans created with encoder_only = 1).  forward: x [B,C,S,S,S] -> "latent" [B*(1+R+L), D] in the compute
+ * dtype = norm(blocks(...)) of every token (hct_mae_plan_activation(plan, "latent")); row b*(1+R+L) is volume b's class token.
+ * backward: stages 0 .. hct_mae_num_backward_stages()-1 like the MAE plan (final norm, blocks in reverse, input assembly + patch
+ * embedding); stage 0 takes dlatent [B*(1+R+L), D] in the compute dtype (the gradient w.r.t. "latent"; rows that do not
+ * feed the loss are zero). */
+int hct_vit_forward(hct_mae_plan*, const void* x, int x_dtype, void* stream);
+int hct_vit_backward_stage(hct_mae_plan*, int stage, const void* dlatent, void* stream);
+int hct_vit_assemble_bwd(const float* dh0, int B, int L, int R, int D, void* dtok, int dtok_dtype, float* dcls, float* dreg, float* dpos,
+                         void* stream);
 /* named activation lookup for parity tests: returns device pointer + shape/dtype, or NULL. */
 const void* hct_mae_plan_activation(const hct_mae_plan*, const char* name, int64_t* rows, int64_t* cols, int* dtype);
 

@@ -479,6 +479,56 @@ def dino_fixture():
                        requires_grad={n: bool(prm.requires_grad) for n, prm in head.named_parameters()},
                        y=sample(y, 256), dx=sample(xh.grad, 256),
                        grads={n: sample(prm.grad, 128) for n, prm in head.named_parameters() if prm.grad is not None})
+    # one whole DINO iteration with the reference's modules (engine_pretrain_dino.py:59-104: teacher on the two global crops,
+    # student on all crops through MultiCropWrapper, DINOLoss, backward, last-layer gradients cancelled, centre update, momentum
+    # teacher update), CPU, no AMP.  Four crops of 24^3 x 3 channels, patch 12, 4 register tokens, qkv bias, sincos table --
+    # the structure of configs/dino/dino_HeadCT.yaml at toy width.
+    from src.models.vit import ViT
+    from src.utils.misc import MultiCropWrapper, cancel_gradients_last_layer
+    kw = dict(in_chans=3, img_size=24, patch_size=12, hidden_size=48, mlp_dim=96, num_layers=2, num_heads=3, patch_embed="conv",
+              pos_embed="sincos", classification=False, num_register_tokens=4, qkv_bias=True)
+    hk = dict(in_dim=48, out_dim=128, use_bn=False, norm_last_layer=True, nlayers=3, hidden_dim=64, bottleneck_dim=32)
+    def build(seed_b, seed_h):
+        b, h = ViT(**kw), DINOHead(**hk)
+        pb = O.make_vit_params({k: list(v.shape) for k, v in b.state_dict().items()}, seed0=seed_b)
+        b.load_state_dict(pb, strict=True)
+        ph = D.make_head_params(48, 128, 64, 32, seed_h)
+        assert list(h.state_dict().keys()) == list(ph.keys())
+        h.load_state_dict(ph, strict=True)
+        return MultiCropWrapper(b, h), pb, ph
+    student, sb, sh = build(700, 750)
+    teacher, tb, th = build(800, 850)
+    Bc, V = 2, 4
+    crops = [u((Bc, 3, 24, 24, 24), 900 + i, 0.0, 1.0) for i in range(V)]
+    crit = DINOLoss(128, V, 0.04, 0.07, 3, 10)
+    crit.center.copy_(u((1, 128), 910, -0.2, 0.2))
+    center0 = crit.center.clone()
+    student.train(); teacher.train()
+    dist.all_reduce, dist.get_world_size = (lambda t, *a, **k: None), (lambda *a, **k: 1)
+    try:
+        with torch.no_grad():
+            t_out = teacher(crops[:2])['dino_output']
+        s_out = student(crops)['dino_output']
+        loss = crit(s_out, t_out, 0)
+    finally:
+        dist.all_reduce, dist.get_world_size = real_ar, real_ws
+    loss.backward()
+    cancel_gradients_last_layer(0, student, 1)
+    o_loss, o_gb, o_gh, o_center = D.dino_step(sb, sh, tb, th, crops, center0, patch=12, heads=3, layers=2, student_temp=0.1,
+                                               teacher_temp=float(crit.teacher_temp_schedule[0]))
+    assert abs(float(o_loss) - float(loss)) < 2e-6 * abs(float(loss)), (float(o_loss), float(loss))
+    ref_g = {n: p.grad for n, p in student.named_parameters() if p.grad is not None}
+    for n, g_ in ref_g.items():
+        o = o_gb[n[len("backbone."):]] if n.startswith("backbone.") else o_gh[n[len("head."):]]
+        assert float((o - g_).norm() / (g_.norm() + 1e-30)) < 2e-5, n
+    assert not any("last_layer" in n for n in ref_g) and not any("last_layer" in n for n in o_gh)
+    assert torch.allclose(o_center, crit.center, rtol=1e-4, atol=1e-6)  # the oracle's teacher logits differ in the last bits
+    _update_momentum_encoder(student, teacher, 0.996)
+    out["step"] = dict(vit=kw, head=hk, batch=Bc, crops=V, backbone_seed=[700, 800], head_seed=[750, 850], crop_seed0=900, center_seed=910,
+                       teacher_temp=float(crit.teacher_temp_schedule[0]), loss=float(loss), logits=sample(s_out, 256),
+                       grads={n: sample(g_, 96) for n, g_ in ref_g.items()}, center_after=sample(crit.center, 128),
+                       teacher_after={n: sample(p, 32) for n, p in list(teacher.named_parameters())[:6]},
+                       backbone_keys=[k for k in student.backbone.state_dict().keys()])
     with open(os.path.join(HERE, "dino.json"), "w") as f:
         json.dump(out, f)
 

@@ -75,3 +75,73 @@ def test_momentum_encoder_update_is_bit_exact(lib, cuda):
     kd = big_k.to(cuda)
     ema_update_(kd, big_q.to(cuda), 0.9995)
     assert torch.equal(kd.cpu(), ref[0])
+
+
+def _build_pair(fx, dev, dtype, which):
+    """MultiCropWrapper(ViTBackbone, DINOHead) with the fixture's hash weights (which = 0 student, 1 teacher)."""
+    from headct_foundation_amd.dino_model import DINOHead, MultiCropWrapper, ViTBackbone
+    vk, hk = dict(fx["vit"]), dict(fx["head"])
+    b = ViTBackbone(**vk, compute_dtype=dtype)
+    assert list(b.state_dict().keys()) == fx["backbone_keys"]  # the reference ViT's names and registration order
+    pb = O.make_vit_params({k: list(v.shape) for k, v in b.state_dict().items()}, seed0=fx["backbone_seed"][which])
+    b.load_state_dict(pb, strict=True)
+    h = DINOHead(**hk, compute_dtype=dtype)
+    ph = D.make_head_params(hk["in_dim"], hk["out_dim"], hk["hidden_dim"], hk["bottleneck_dim"], fx["head_seed"][which])
+    assert list(h.state_dict().keys()) == list(ph.keys())
+    h.load_state_dict(ph, strict=True)
+    return MultiCropWrapper(b, h).to(dev), pb, ph
+
+
+@pytest.mark.parametrize("dtype,tol_loss,tol_grad", [("fp32", 2e-5, 1e-3), ("bf16", 2e-3, 5e-2)])
+def test_dino_step_vs_reference_fixture(lib, cuda, dtype, tol_loss, tol_grad):
+    """One DINO iteration (engine_pretrain_dino.py:59-104: teacher on the two global crops, student on all crops through
+    MultiCropWrapper, DINOLoss, backward, last-layer gradients cancelled, centre update, momentum-teacher update) on the HIP path
+    against the fixture produced by the reference's own ViT / DINOHead / MultiCropWrapper / DINOLoss (tests/golden/dino.json,
+    'step') and against the oracle.  fp32 mode: loss 2e-5, every gradient 1e-3 relative L2; bf16 mode: 2e-3 / 5e-2."""
+    from headct_foundation_amd.dino import DINOLoss, update_momentum_encoder
+    fx = json.load(open(os.path.join(GOLDEN, "dino.json")))["step"]
+    student, sb, sh = _build_pair(fx, cuda, dtype, 0)
+    teacher, tb, th = _build_pair(fx, cuda, dtype, 1)
+    V, Bc = fx["crops"], fx["batch"]
+    S = fx["vit"]["img_size"]
+    crops = [_hu((Bc, 3, S, S, S), fx["crop_seed0"] + i, 0.0, 1.0) for i in range(V)]
+    center0 = _hu((1, fx["head"]["out_dim"]), fx["center_seed"], -0.2, 0.2)
+    crit = DINOLoss(fx["head"]["out_dim"], V, 0.04, 0.07, 3, 10).to(cuda)
+    crit.center.copy_(center0)
+    dcrops = [c.to(cuda) for c in crops]
+    with torch.no_grad():
+        t_out = teacher(dcrops[:2])['dino_output']
+    s_out = student(dcrops)['dino_output']
+    loss = crit(s_out.float(), t_out.float(), 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - fx["loss"]) < tol_loss * abs(fx["loss"]), (float(loss), fx["loss"])
+    got, want, l2, l2w = sample_of(s_out.float(), fx["logits"])
+    assert abs(l2 - l2w) < (1e-4 if dtype == "fp32" else 2e-2) * l2w
+    grads = {("backbone." + n): p.grad for n, p in student.backbone.named_parameters() if p.grad is not None}
+    grads.update({("head." + n): p.grad for n, p in student.head.named_parameters() if p.grad is not None})
+    # cancel_gradients_last_layer (misc.py:366-371): the fixture was taken at epoch 0 < FREEZE_LAST_LAYER
+    grads = {n: g for n, g in grads.items() if "last_layer" not in n}
+    assert set(grads) == set(fx["grads"]), set(grads) ^ set(fx["grads"])
+    o_loss, o_gb, o_gh, o_center = D.dino_step(sb, sh, tb, th, crops, center0, patch=fx["vit"]["patch_size"], heads=fx["vit"]["num_heads"],
+                                               layers=fx["vit"]["num_layers"], student_temp=0.1, teacher_temp=fx["teacher_temp"])
+    worst = []
+    for n, g in grads.items():
+        o = o_gb[n[len("backbone."):]] if n.startswith("backbone.") else o_gh[n[len("head."):]]
+        worst.append((rel_err(g.float(), o), n))
+        got, want, l2, l2w = sample_of(g.float(), fx["grads"][n])
+        if not n.endswith("qkv.bias"):
+            assert abs(l2 - l2w) <= tol_grad * l2w + 1e-12, n
+    bad = [w for w in worst if not w[1].endswith("qkv.bias")]
+    assert max(bad)[0] < tol_grad, sorted(bad)[-5:]
+    got, want, _, _ = sample_of(crit.center, fx["center_after"])
+    assert torch.allclose(got, want, rtol=1e-3 if dtype == "fp32" else 2e-2, atol=1e-5 if dtype == "fp32" else 2e-3)
+    # momentum teacher: one fused launch per flat buffer (backbone, head)
+    update_momentum_encoder(student.backbone, teacher.backbone, 0.996)
+    update_momentum_encoder(student.head, teacher.head, 0.996)
+    torch.cuda.synchronize()
+    tnamed = dict(("backbone." + n, p) for n, p in teacher.backbone.named_parameters())
+    tnamed.update(("head." + n, p) for n, p in teacher.head.named_parameters())
+    for n, entry in fx["teacher_after"].items():
+        got, want, _, _ = sample_of(tnamed[n], entry)
+        assert torch.equal(got, want), n  # exact: the same fp32 operations in the same order
