@@ -117,3 +117,79 @@ def update_momentum_encoder(model, momentum_model, m: float) -> None:
 def ema_update_(k: torch.Tensor, q: torch.Tensor, m: float) -> None:
     """The same update on two arbitrary contiguous fp32 GPU tensors (numel % 4 == 0)."""
     _lib.check(_lib.load().hct_ema_update(k.data_ptr(), q.data_ptr(), k.numel(), float(m), _st()), "hct_ema_update")
+
+
+class DinoOptimizer:
+    """AdamW over the student's two flat parameter buffers (backbone plan + projection head): two fused HipAdamW launches that
+    share the learning rate and weight decay of `param_groups[0]` (what the LR scheduler and the weight-decay schedule write to).
+    The reference builds one torch AdamW over MultiCropWrapper.parameters() (main_pretrain_dino.py:219); the arithmetic per
+    parameter is the same, the state dict is split in two ({'backbone': ..., 'head': ...})."""
+
+    def __init__(self, model, lr, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8):
+        from .optim import HipAdamW
+        m = model.module if hasattr(model, "module") else model
+        self.primary = HipAdamW(m.backbone, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.secondary = HipAdamW(m.head, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+    @property
+    def param_groups(self):
+        return self.primary.param_groups
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.primary.zero_grad(set_to_none=set_to_none)
+        self.secondary.zero_grad(set_to_none=set_to_none)
+
+    def step(self):
+        for k in ("lr", "weight_decay", "betas", "eps"):
+            self.secondary.param_groups[0][k] = self.primary.param_groups[0][k]
+        self.primary.step()
+        self.secondary.step()
+
+    def state_dict(self):
+        return {"backbone": self.primary.state_dict(), "head": self.secondary.state_dict()}
+
+    def load_state_dict(self, sd):
+        self.primary.load_state_dict(sd["backbone"])
+        self.secondary.load_state_dict(sd["head"])
+
+
+class DinoDataParallel(nn.Module):
+    """Data-parallel wrapper of a MultiCropWrapper: the backbone's flat gradient is all-reduced in buckets while its staged backward
+    is still running (ddp.DistributedDataParallel), the head's (8 % of the parameters) in one all-reduce that the engine issues
+    right after `loss.backward()` (`reduce_head_gradients`).  Rank 0's parameters are broadcast at construction."""
+
+    def __init__(self, module, device_ids=None, broadcast_buffers: bool = False, find_unused_parameters: bool = False, bucket_cap_mb: float = 64.0):
+        super().__init__()
+        from .ddp import DistributedDataParallel
+        self.module = module
+        self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self._backbone_ddp = DistributedDataParallel(module.backbone, bucket_cap_mb=bucket_cap_mb)
+        if self.world_size > 1:
+            dist.broadcast(module.head._flat, src=0)
+            module.head.mark_weights_updated()
+
+    def forward(self, x):
+        return self.module(x)
+
+    def reduce_head_gradients(self) -> None:
+        if self.world_size > 1:
+            g = self.module.head._flat_grad
+            dist.all_reduce(g)
+            g.div_(self.world_size)
+
+
+class SyntheticCrops:
+    """`n_batches` pre-generated multi-crop batches on the device: each a list of `n_crops` tensors [B, C, S, S, S] in [0, 1) (the
+    reference resizes global and local crops to one size, transforms.py:75-97, so one backbone pass serves all crops)."""
+
+    def __init__(self, n_batches, batch_size, n_crops, in_chans, size, device, seed=0):
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
+        self.batches = [[torch.rand(batch_size, in_chans, size, size, size, device=device, generator=gen) for _ in range(n_crops)]
+                        for _ in range(n_batches)]
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        return iter(self.batches)

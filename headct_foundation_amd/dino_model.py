@@ -368,6 +368,13 @@ class MultiCropWrapper(nn.Module):
         super().__init__()
         self.backbone, self.head = backbone, head
 
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=False)
+        for m in (self.backbone, self.head):  # the children's fp32 masters changed underneath their bf16 working copies
+            if hasattr(m, "mark_weights_updated"):
+                m.mark_weights_updated()
+        return out
+
     def forward(self, x):
         if not isinstance(x, list):
             x = [x]

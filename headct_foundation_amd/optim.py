@@ -167,7 +167,14 @@ class HipAdamW(torch.optim.Optimizer):
         self._step_count_fused += 1
         lib = _lib.load()
         coef = st.coef.data_ptr() if st.coef_pending else None
-        # parameters that received no gradient this step are skipped like torch does (p.grad is None)
+        # parameters that received no gradient this step are skipped like torch does (p.grad is None): the skip mask follows the
+        # set of gradient-less parameters and is re-uploaded only when that set changes (e.g. the DINO prototype layer, whose
+        # gradients are cancelled during the first epochs)
+        named = getattr(m, "_named_cache", None) or dict(m.named_parameters())
+        key = tuple((not named[n].requires_grad) or named[n].grad is None for n in st.names)
+        if getattr(st, "skip_key", None) != key:
+            st.skip = torch.tensor([1 if k else 0 for k in key], dtype=torch.uint8, device=m._flat.device)
+            st.skip_key = key
         _lib.check(lib.hct_adamw_step(
             m._flat.data_ptr(), m._flat_grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), st.seg_off.data_ptr(), coef,
             st.skip.data_ptr(), st.nseg, st.total, float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]),

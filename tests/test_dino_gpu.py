@@ -145,3 +145,27 @@ def test_dino_step_vs_reference_fixture(lib, cuda, dtype, tol_loss, tol_grad):
     for n, entry in fx["teacher_after"].items():
         got, want, _, _ = sample_of(tnamed[n], entry)
         assert torch.equal(got, want), n  # exact: the same fp32 operations in the same order
+
+
+def test_main_pretrain_dino_plumbing_run(cuda, tmp_path):
+    """python -m torch.distributed.run --nproc-per-node 1 main_pretrain_dino.py ... (toy ViT, 2 + 2 crops of 24^3 x 3ch, 2 epochs with
+    validation, checkpoints with the momentum model, test): the reference's entry-point flow on the HIP path."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29537",
+           os.path.join(root, "main_pretrain_dino.py"), "--local_rank", "0", "--model_name", "dino", "--batch_size", "2", "--max_epochs", "2",
+           "--base_lr", "5e-4", "--cfg", os.path.join(root, "configs/dino/dino_tiny_plumbing.yaml"), "--optimizer", "AdamW", "--scheduler", "cosine",
+           "--opts", "MODEL.DIR", str(tmp_path / "ckpt"), "LOG.OUTPUT_DIR", str(tmp_path / "log"), "OUTPUT", str(tmp_path / "json")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "train completed" in r.stdout and "test completed" in r.stdout
+    ck = torch.load(tmp_path / "ckpt" / "last_dino_tiny.pt", map_location="cpu", weights_only=True)
+    assert sorted(ck.keys()) == ["best_loss", "epoch", "momentum_model_state_dict", "optimizer", "scheduler", "state_dict"]
+    assert "module.backbone.blocks.0.attn.qkv.weight" in ck["state_dict"] and "module.head.last_layer.weight_v" in ck["state_dict"]
+    assert ck["momentum_model_state_dict"] is not None and set(ck["momentum_model_state_dict"]) == set(ck["state_dict"])
+    # the teacher follows the student by the momentum update only: close to it, not equal
+    a, b = ck["state_dict"]["module.backbone.norm.weight"], ck["momentum_model_state_dict"]["module.backbone.norm.weight"]
+    assert not torch.equal(a, b) and float((a - b).abs().max()) < 1e-2
+    assert (tmp_path / "ckpt" / "best_dino_tiny.pt").exists()
