@@ -61,6 +61,105 @@ def algorithmic_train_flops_per_volume(c) -> float:
     return 3.0 * fwd
 
 
+# BASELINE config #5 (`--config dino`): ViT-B/12^3 student + momentum teacher on 96^3 x 3-channel crops (configs/dino/dino_HeadCT.yaml: 512
+# patches + class + 4 register tokens = 517 tokens, qkv bias, sincos table), 2 global + 8 local crops all at 96^3 (the reference
+# resizes every crop to the final size, transforms.py:75-97), projection head 768-2048-2048-256-65536.
+DINO = dict(vit=dict(in_chans=3, img_size=96, patch_size=12, hidden_size=768, mlp_dim=3072, num_layers=12, num_heads=12, pos_embed="sincos",
+                     num_register_tokens=4, qkv_bias=True),
+            head=dict(in_dim=768, out_dim=65536, hidden_dim=2048, bottleneck_dim=256), crops=10)
+
+
+def dino_train_flops_per_volume(c) -> float:
+    """Algorithmic FLOPs of one DINO iteration per input volume (multiply-add = 2; GEMMs + QK^T + PV): student forward + backward
+    (3 x forward) on all crops, teacher forward on the two global crops, both through backbone and head."""
+    v, h = c["vit"], c["head"]
+    L = (v["img_size"] // v["patch_size"]) ** 3
+    N = 1 + v["num_register_tokens"] + L
+    D, M = v["hidden_size"], v["mlp_dim"]
+    pd = v["in_chans"] * v["patch_size"] ** 3
+    backbone = 2.0 * L * pd * D + v["num_layers"] * (N * (8 * D * D + 4 * D * M) + 4 * N * N * D)
+    head = 2.0 * (h["in_dim"] * h["hidden_dim"] + h["hidden_dim"] ** 2 + h["hidden_dim"] * h["bottleneck_dim"] + h["bottleneck_dim"] * h["out_dim"])
+    return (3.0 * c["crops"] + 2.0) * (backbone + head)
+
+
+def run_dino(args, world, rank, device):
+    """One DINO training iteration per step (engine_pretrain_dino.py:59-104): weight-decay schedule, teacher forward (2 crops), student
+    forward (10 crops), DINO loss + centre update, backward, AdamW on backbone + head, LR step, momentum-teacher update."""
+    import torch.distributed as dist
+    from headct_foundation_amd.dino import DINOLoss, DinoDataParallel, DinoOptimizer, update_momentum_encoder, wd_cosine_scheduler
+    from headct_foundation_amd.dino_model import DINOHead, MultiCropWrapper, ViTBackbone
+    from headct_foundation_amd.lr_sched import get_cosine_schedule_with_warmup
+    B, G, V = args.batch or 8, world, DINO["crops"]
+    torch.manual_seed(42)
+    mk = lambda: MultiCropWrapper(ViTBackbone(**DINO["vit"], compute_dtype=args.dtype), DINOHead(**DINO["head"], compute_dtype=args.dtype)).to(device)
+    student, teacher = mk(), mk()
+    teacher.load_state_dict(student.state_dict())
+    for p in teacher.parameters():
+        p.requires_grad_(False)
+    model, momentum_model = DinoDataParallel(student), DinoDataParallel(teacher)
+    total = max(1000, args.steps + args.warmup)
+    lr = 5e-4 * B * G / 256
+    opt = DinoOptimizer(model, lr=lr, betas=(0.9, 0.999), weight_decay=0.04)
+    sched = get_cosine_schedule_with_warmup(opt.primary, int(0.1 * total), total, lr_end=lr * 1e-3)
+    wd = wd_cosine_scheduler(0.04, 0.4, 1, total)
+    mom = wd_cosine_scheduler(0.999, 1.0, 1, total)
+    crit = DINOLoss(DINO["head"]["out_dim"], V, 0.04, 0.04, 30, 200).to(device)
+    torch.manual_seed(42 + rank)
+    S = DINO["vit"]["img_size"]
+    pool = [[torch.rand(B, 3, S, S, S, device=device) for _ in range(V)] for _ in range(2)]
+    losses = torch.zeros(args.steps + args.warmup, device=device)
+
+    def step(i):
+        opt.param_groups[0]["weight_decay"] = float(wd[i])
+        opt.zero_grad()
+        crops = pool[i % 2]
+        with torch.no_grad():
+            t_out = momentum_model(crops[:2])['dino_output']
+        s_out = model(crops)['dino_output']
+        loss = crit(s_out.float(), t_out.float(), 0)
+        loss.backward()
+        model.reduce_head_gradients()
+        opt.step()
+        sched.step()
+        update_momentum_encoder(student.backbone, teacher.backbone, float(mom[i]))
+        update_momentum_encoder(student.head, teacher.head, float(mom[i]))
+        losses[i] = loss.detach()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    lv = losses.cpu()
+    if not torch.isfinite(lv).all():
+        raise SystemExit(f"non-finite loss during the benchmark: {lv.tolist()}")
+    if rank == 0:
+        fl = dino_train_flops_per_volume(DINO)
+        vols = B * G * args.steps
+        print(json.dumps({
+            "metric": "CT-volumes/sec DINO pretrain step (ViT-B/12^3 student + teacher, 96^3x3ch, 2 global + 8 local crops)",
+            "value": round(vols / elapsed, 2), "unit": "CT-volumes/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config #5: DINO, ViT-B/12^3 (517 tokens, 4 register tokens), head 768-2048-2048-256-65536, full iteration",
+                       "per_gpu_batch": B, "global_batch": B * G, "crops_per_volume": V, "parallelism": f"dp{G}",
+                       "algorithmic_GFLOP_per_volume": round(fl / 1e9, 1)},
+            "step_mfma_frac": round(vols / elapsed * fl / G / 1e12 / PEAK_BF16_TFLOPS, 4), "roofline": None,
+            "loss_first": round(float(lv[0]), 5), "loss_last": round(float(lv[-1]), 5)}), flush=True)
+
+
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (separate passes cannot run
     inside the timed region); None if no summary is present."""
@@ -117,8 +216,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="vitb", choices=sorted(WORKLOADS), help="vitb = BASELINE config #2 (the headline metric), vitl = config #4")
-    ap.add_argument("--batch", type=int, default=0, help="volumes per GPU (default: 256 for vitb, 64 for vitl)")
+    ap.add_argument("--config", default="vitb", choices=sorted(WORKLOADS) + ["dino"],
+                    help="vitb = BASELINE config #2 (the headline metric), vitl = config #4, dino = config #5")
+    ap.add_argument("--batch", type=int, default=0, help="volumes per GPU (default: 256 for vitb, 64 for vitl, 8 for dino)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket the dominant kernel with HIP events")
@@ -155,6 +255,11 @@ def main():
             dist.init_process_group("nccl", device_id=device)
 
     lib = _lib.load()
+    if args.config == "dino":
+        run_dino(args, world, rank, device)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     arch, default_batch, workload, metric = WORKLOADS[args.config]
     B, G = args.batch or default_batch, world
     S = arch["input_size"]

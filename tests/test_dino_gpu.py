@@ -169,3 +169,50 @@ def test_main_pretrain_dino_plumbing_run(cuda, tmp_path):
     a, b = ck["state_dict"]["module.backbone.norm.weight"], ck["momentum_model_state_dict"]["module.backbone.norm.weight"]
     assert not torch.equal(a, b) and float((a - b).abs().max()) < 1e-2
     assert (tmp_path / "ckpt" / "best_dino_tiny.pt").exists()
+
+
+def test_dino_full_size_step_properties(lib, cuda):
+    """BASELINE config #5 at full width and depth (ViT-B/12^3: 517 tokens, 12 blocks, head 768-2048-2048-256-65536, 2 global + 8
+    local crops of 96^3 x 3 channels, bf16): too large for the oracle, so the size-independent properties -- the iteration is
+    bit-reproducible, every trainable parameter receives a finite gradient, the frozen prototype scale receives none, an optimizer
+    step on the same batch lowers the loss, and after the momentum update the teacher lies between its old value and the student."""
+    import bench
+    from headct_foundation_amd.dino import DINOLoss, DinoOptimizer, update_momentum_encoder
+    from headct_foundation_amd.dino_model import DINOHead, MultiCropWrapper, ViTBackbone
+    torch.manual_seed(3)
+    mk = lambda: MultiCropWrapper(ViTBackbone(**bench.DINO["vit"], compute_dtype="bf16"), DINOHead(**bench.DINO["head"], compute_dtype="bf16")).to(cuda)
+    student, teacher = mk(), mk()
+    teacher.load_state_dict(student.state_dict())
+    B, V = 2, bench.DINO["crops"]
+    g = torch.Generator(device=cuda)
+    g.manual_seed(5)
+    crops = [torch.rand(B, 3, 96, 96, 96, device=cuda, generator=g) for _ in range(V)]
+    crit = DINOLoss(65536, V, 0.04, 0.04, 30, 200).to(cuda)
+
+    def iteration():
+        for p in student.parameters():
+            p.grad = None
+        crit.center.zero_()
+        with torch.no_grad():
+            t_out = teacher(crops[:2])['dino_output']
+        loss = crit(student(crops)['dino_output'].float(), t_out.float(), 0)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {n: p.grad.detach().clone() for n, p in student.named_parameters() if p.grad is not None}
+
+    l1, g1 = iteration()
+    l2, g2 = iteration()
+    assert l1 == l2 and all(torch.equal(g1[k], g2[k]) for k in g1), "the DINO iteration is not bit-reproducible"
+    assert 9.5 < l1 < 11.5  # around ln(65536) = 11.09 at initialisation (student near uniform over the prototypes)
+    trainable = [n for n, p in student.named_parameters() if p.requires_grad]
+    assert set(g1) == set(trainable) and "head.last_layer.weight_g" not in g1
+    assert all(torch.isfinite(v).all() for v in g1.values()) and all(float(v.abs().max()) > 0 for v in g1.values())
+    opt = DinoOptimizer(student, lr=2e-4, weight_decay=0.04)
+    opt.step()
+    before = teacher.backbone.norm.weight.detach().clone()
+    update_momentum_encoder(student.backbone, teacher.backbone, 0.9)
+    after, stud = teacher.backbone.norm.weight.detach(), student.backbone.norm.weight.detach()
+    assert torch.allclose(after, before * 0.9 + stud * (1 - 0.9), rtol=1e-6, atol=1e-7)
+    teacher.load_state_dict(student.state_dict())  # identical networks see identical logits on the global crops ...
+    l3, _ = iteration()
+    assert l3 < l1, (l1, l3)
