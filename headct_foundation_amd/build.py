@@ -14,6 +14,8 @@ SOURCES = ["elementwise.hip", "optim.hip", "gemm.hip", "attention_simple.hip", "
            "mae_plan.hip", "heads.hip", "prof.hip", "dino.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "prof.h"), os.path.join(os.path.dirname(HERE), "include", "headct_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-inline-asm", "-ffp-contract=off"]
+# packed f32 VALU (v_pk_mul_f32 / v_pk_fma_f32 from the SLP vectoriser) issues slower than the two scalar operations beside MFMAs
+FILE_FLAGS = {"attention_mfma.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -42,7 +44,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
     def cc(job):
         sp, op = job
-        cmd = [hipcc] + FLAGS + ["-c", sp, "-o", op]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(sp), []) + ["-c", sp, "-o", op]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {sp}:\n{r.stdout}\n{r.stderr}")
@@ -67,7 +69,7 @@ def build_stamps_library(tag: str = "stamps", defines=("-DHCT_STAMPS",), src: st
     build_library()
     hipcc = _hipcc()
     op = os.path.join(OBJ, f"{src[:-4]}_{tag}.o")
-    r = subprocess.run([hipcc] + FLAGS + list(defines) + ["-c", os.path.join(CSRC, src), "-o", op], capture_output=True, text=True)
+    r = subprocess.run([hipcc] + FLAGS + FILE_FLAGS.get(src, []) + list(defines) + ["-c", os.path.join(CSRC, src), "-o", op], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed (stamps):\n{r.stdout}\n{r.stderr}")
     objs = [op if s == src else os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]

@@ -14,9 +14,11 @@
 //     FLOPs, so the recompute is cheaper than cross-wave reductions.
 #include "common.h"
 
+#include <type_traits>
+
 namespace hct {
 
-int g_attn_bwd3 = 2;  // which shapes use the key-owner five-product backward: bit0 head dim 48 (<= 256 tokens), bit1 head dim 64 (<= 192 tokens)
+int g_attn_bwd3 = 6;  // which shapes use the key-owner five-product backward: bit0 head dim 48 (<= 256 tokens, bwd3), bit1 head dim 64 (<= 192 tokens, bwd3), bit2 head dim 48 with 193 .. 224 tokens (persistent bwd4)
 int g_attn_dbg = 0;  // timing experiments on the backward kernel: bit0 skip key-owner pass, bit1 skip query-owner pass
 
 namespace {
@@ -879,6 +881,301 @@ __global__ void __launch_bounds__(GS * 64, WPS) attn_bwd3_kernel(const bf16* __r
 template <int DH>
 inline size_t bwd3_lds(int Npad) { return (size_t)3 * Npad * HeadImg<DH>::kRow + (size_t)2 * Npad * 32 + (size_t)2 * Npad * sizeof(float); }
 
+
+// ============================================================================================================
+// Backward, PERSISTENT key-owner form (bwd4): the five-product algorithm of bwd3 with the three things its phase stamps
+// asked for (attention):
+//   * one 8-wave workgroup per CU walks the (batch, head) items; the NEXT item's Q / dO / K images (LDS-DMA into the other
+//     LDS buffer), its own V rows, its O rows and lse values (registers) are in flight while the current item is computed,
+//     so no workgroup ever sits in a load phase;
+//   * each wave owns two 16-key tiles (256 registers per wave: every streamed fragment of a query block is fetched once,
+//     nothing spills); delta = rowsum(dO . O) is formed from the dO image already in LDS and the prefetched O registers;
+//   * dS^T is double-buffered, so the dQ product of query block j-1 runs in the same barrier interval as the main part of
+//     block j (one barrier per block), and the two waves of a SIMD take the two parts in opposite order: one is in the
+//     VALU-heavy S / P / dS part while its partner streams the MFMA-only dQ product.
+// The operand stream is inline-asm LDS-DMA (hipcc would drain vmcnt before the first LDS read behind a builtin DMA).
+typedef __attribute__((ext_vector_type(4))) int attn_i32x4;
+__device__ __forceinline__ attn_i32x4 attn_srd(const void* base, int64_t bytes) {
+  const uint64_t pa = (uint64_t)base;
+  const uint32_t rec = bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (bytes < 0 ? 0u : (uint32_t)bytes);
+  return attn_i32x4{(int)__builtin_amdgcn_readfirstlane((uint32_t)pa), (int)(__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) & 0xFFFF),
+                    (int)__builtin_amdgcn_readfirstlane(rec), 0x00020000};
+}
+__device__ __forceinline__ void attn_dma16(attn_i32x4 rsrc, uint32_t lds_base, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+
+template <int DH, int Npad>
+__global__ void __launch_bounds__(512, 2) attn_bwd4_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                           const bf16* __restrict__ d_o, const float* __restrict__ lse, int N, int H,
+                                                           bf16* __restrict__ dqkv, int nbh, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ROW = HeadImg<DH>::kRow, CH = HeadImg<DH>::kChunks, ND = DH / 16, KT = 2;
+  constexpr int img = Npad * ROW;                       // one image
+  constexpr int bufsz = 3 * img + 32 + 2 * Npad * 4;    // Q | dO | K | 32 zero bytes (the streamed K fragment of the last row reads them) | lse | delta
+  unsigned char* const dsT0 = smem + 2 * bufsz;     // dS^T, two buffers of 2 * Npad * 32
+  constexpr int dstsz = 2 * Npad * 32;
+  const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4;
+  const int64_t rs = (int64_t)3 * H * DH, os = (int64_t)H * DH;
+  const float scale = rsqrtf((float)DH);
+  const float scale2 = scale * 1.44269504088896340736f;
+  const int key_base = wave * (KT * 16);
+  constexpr int nqb = Npad >> 5;
+  constexpr int pieces = Npad * CH / 64;                // 1-KiB DMA pieces per image
+  constexpr int MAXP = 3;                           // ceil(pieces / 8) for Npad <= 256
+  // Per-lane offsets used only between two items (DMA sources, register prefetch, dK / dV rows) are recomputed there from an
+  // opaque copy of the lane id: hoisted out of the item loop they were spilled to scratch, and every reload is a vector-memory
+  // operation whose wait also drains the stores in flight.
+  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  if (threadIdx.x < 16) {  // the two 32-byte pads
+    *reinterpret_cast<uint32_t*>(smem + (threadIdx.x >> 3) * bufsz + 3 * img + (threadIdx.x & 7) * 4) = 0u;
+  }
+  auto item_bh = [&](int item) {  // XCD-contiguous walk: the workgroups of one XCD work on neighbouring heads at any time
+    const int xcd = item & 7, q = nbh >> 3, r = nbh & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (item >> 3);
+  };
+  // dQ tiles (query half hh, d-tile dt) of a query block go to waves 4 .. 7, which run them BEFORE their main part: the two waves
+  // of a SIMD are then half a block apart (one reads fragments / runs the MFMA-only dQ product while the other is in the
+  // VALU-heavy P / dS part) and the fragment reads after a barrier come in two bursts.  With 14 key tiles (Npad = 224) wave 7
+  // owns no keys and takes one query half whole.
+  int dq_hh, dq_dt0, dq_n;
+  if (key_base >= Npad) { dq_hh = 0; dq_dt0 = 0; dq_n = ND; }
+  else if (8 * KT * 16 > Npad) { dq_hh = 1; dq_dt0 = wave - 4; dq_n = (wave >= 4 && wave < 4 + ND) ? 1 : 0; }
+  else { dq_hh = (wave - 2) / ND; dq_dt0 = (wave - 2) - dq_hh * ND; dq_n = wave >= 2 ? 1 : 0; }
+
+  auto prefetch_images = [&](int item, int buf) {
+    const int bh = item_bh(item), b = bh / H, h = bh - b * H;
+    const bf16* qb = qkv + (int64_t)b * N * rs + h * DH;
+    const bf16* dob = d_o + (int64_t)b * N * os + h * DH;
+    const attn_i32x4 rq = attn_srd(qb, ((int64_t)(N - 1) * rs + DH) * 2);
+    const attn_i32x4 rk = attn_srd(qb + H * DH, ((int64_t)(N - 1) * rs + DH) * 2);
+    const attn_i32x4 rd = attn_srd(dob, ((int64_t)(N - 1) * os + DH) * 2);
+    const uint32_t base = lds0 + buf * bufsz;
+    const int ln = opaque(lane);
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int p = wave + 8 * i;
+      if (p < pieces) {  // wave-uniform; piece p = 64 consecutive 16-byte chunks of the image, lane -> (row, slot)
+        const int ci = p * 64 + ln, row = ci / CH, slot = ci - row * CH;
+        const uint32_t src = (uint32_t)((DH == 48 ? slot : (slot ^ ((row >> 1) & 7))) * 16);
+        const uint32_t vq = (uint32_t)row * (uint32_t)(rs * 2) + src, vd = (uint32_t)row * (uint32_t)(os * 2) + src;
+        attn_dma16(rq, base + p * 1024, vq);
+        attn_dma16(rd, base + img + p * 1024, vd);
+        attn_dma16(rk, base + 2 * img + p * 1024, vq);
+      }
+    }
+  };
+  // own V rows, O chunks (for delta) and lse values of an item, into registers
+  RowFrag<DH> vfN[KT];
+  bf16x8 oN[4];
+  float lN = 0.f;
+  auto prefetch_regs = [&](int item) {
+    const int bh = item_bh(item), b = bh / H, h = bh - b * H;
+    const bf16* vb = qkv + (int64_t)b * N * rs + 2 * H * DH + h * DH;
+    const int ln = opaque(lane), tid = wave * 64 + ln;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) vfN[t] = rows_global<DH>(vb, rs, key_base + t * 16, ln, N);
+    const bf16* ob = o + (int64_t)b * N * os + h * DH;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + u * 512, r = idx >> 3, c = idx & 7;
+      oN[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (r < N && c * 8 < DH) oN[u] = *reinterpret_cast<const bf16x8*>(ob + (int64_t)r * os + c * 8);
+    }
+    lN = tid < N ? lse[(int64_t)bh * N + tid] : 0.f;
+  };
+
+  // (testing, dbg & 0x80) phase stamps of workgroup 0, waves 0 / 4 / 7, first four items: 10 per item, kept in the spare LDS
+  // behind the dS^T buffers and dumped one per token row into the dQ slice of the workgroup's last item
+  unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(dsT0 + 2 * dstsz);
+  const int swave = wave == 0 ? 0 : wave == 4 ? 1 : wave == 7 ? 2 : -1;
+#define BWD4_STAMP(k_) do { if ((dbg & 0x80) && blockIdx.x == 0 && swave >= 0 && it < 4 && lane == 0) { __builtin_amdgcn_sched_barrier(0); stamps[(swave * 4 + it) * 10 + (k_)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+  int item = blockIdx.x;
+  if (item >= nbh) return;
+  prefetch_images(item, 0);
+  prefetch_regs(item);
+  for (int it = 0; item < nbh; item += gridDim.x, ++it) {
+    const int cur = it & 1;
+    unsigned char* Qimg = smem + cur * bufsz;
+    unsigned char* Dimg = Qimg + img;
+    unsigned char* Kimg = Dimg + img;
+    float* sLse = reinterpret_cast<float*>(Kimg + img + 32);
+    float* sDel = sLse + Npad;
+    const int bh = item_bh(item), b = bh / H, h = bh - b * H;
+    // this item's prefetch has landed: own DMA retired, then every wave's
+    BWD4_STAMP(0);
+    // A use of the YOUNGEST prefetched value: the compiler's counted vmcnt wait for it also covers the older loads and DMA pieces
+    // (vector-memory operations retire in issue order) but leaves the previous item's dK / dV stores, issued after it, in flight.
+    asm volatile("" ::"v"(lN) : "memory");
+    BWD4_STAMP(1);
+    __builtin_amdgcn_s_barrier();
+    BWD4_STAMP(2);
+    RowFrag<DH> vf[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) vf[t] = vfN[t];
+    // delta[r] = sum_d dO[r,d] O[r,d] from the dO image and the prefetched O registers (8 lanes per row), stored times the
+    // softmax scale: dS = P (dP scale - delta scale)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = threadIdx.x + u * 512, r = idx >> 3, c = idx & 7;
+      float part = 0.f;
+      if (idx < Npad * 8 && c * 8 < DH) {
+        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(Dimg + HeadImg<DH>::off(r, c));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += (float)oN[u][e] * (float)dv[e];
+      }
+      part += __shfl_xor(part, 1, 64);
+      part += __shfl_xor(part, 2, 64);
+      part += __shfl_xor(part, 4, 64);
+      if (idx < Npad * 8 && c == 0) sDel[r] = r < N ? part * scale : 0.f;
+    }
+    if ((int)threadIdx.x < Npad) sLse[threadIdx.x] = (int)threadIdx.x < N ? lN * 1.44269504088896340736f : INFINITY;  // base 2; +inf: p = 0 on padded query rows
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    BWD4_STAMP(3);
+    const int next = item + gridDim.x;
+    if (next < nbh) prefetch_images(next, cur ^ 1);  // in flight during the whole compute below
+    BWD4_STAMP(4);
+
+    f32x4 dKt[KT][ND], dVt[KT][ND];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) dKt[t][dt] = dVt[t][dt] = f32x4{0, 0, 0, 0};
+
+    auto main_part = [&](int qbk) {
+      const int q0 = qbk * 32;
+      unsigned char* dsT = dsT0 + (qbk & 1) * dstsz;
+      RowFrag<DH> qr[2], dr[2];
+      f32x4 L4[2], D4[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        qr[hh] = rows_lds<DH>(Qimg, q0 + 16 * hh, lane, true);
+        dr[hh] = rows_lds<DH>(Dimg, q0 + 16 * hh, lane, true);
+        L4[hh] = *reinterpret_cast<const f32x4*>(sLse + q0 + 16 * hh + 4 * g);
+        D4[hh] = *reinterpret_cast<const f32x4*>(sDel + q0 + 16 * hh + 4 * g);
+      }
+      bf16x8 qT[ND], dT[ND];
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        qT[dt] = cols_lds<DH>(Qimg, q0, q0 + 16, dt * 16, lane);
+        dT[dt] = cols_lds<DH>(Dimg, q0, q0 + 16, dt * 16, lane);
+      }
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        const int key0 = key_base + t * 16;  // < Npad: Npad is a multiple of 32
+        const RowFrag<DH> kf = rows_lds<DH>(Kimg, key0, lane, false);
+        const int key = key0 + (lane & 15);
+        const float keep = key < N ? 1.f : 0.f;
+        f32x4 P[2], dS[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const f32x4 sacc = mma_rows<DH>(qr[hh], kf, f32x4{0, 0, 0, 0});    // S[q = 4g+r][key = lane&15]
+          const f32x4 dp = mma_rows<DH>(dr[hh], vf[t], f32x4{0, 0, 0, 0});   // dP[q][key]
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            P[hh][r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale2, -L4[hh][r])) * keep;
+            dS[hh][r] = P[hh][r] * fmaf(dp[r], scale, -D4[hh][r]);
+          }
+        }
+        const bf16x8 pa = pack8(P[0], P[1]);
+        const bf16x8 dsa = pack8(dS[0], dS[1]);
+        const bf16x4 d0 = {dsa[0], dsa[1], dsa[2], dsa[3]}, d1 = {dsa[4], dsa[5], dsa[6], dsa[7]};
+        *reinterpret_cast<bf16x4*>(dsT + dst_off(Npad, 0, key, g)) = d0;
+        *reinterpret_cast<bf16x4*>(dsT + dst_off(Npad, 1, key, g)) = d1;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+          dVt[t][dt] = MFMA(dT[dt], pa, dVt[t][dt]);   // dV^T[d][key] += dO^T.P
+          dKt[t][dt] = MFMA(qT[dt], dsa, dKt[t][dt]);  // dK^T[d][key] += Q^T.dS
+        }
+      }
+    };
+    // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] of block qbk, tiles (hh, dt0 .. dt0 + NT - 1): the dS^T fragment is shared
+    auto dq_tiles = [&](int qbk, int hh, int dt0, auto nt_tag, int ln) {
+      constexpr int NT = decltype(nt_tag)::value;
+      const unsigned char* dsT = dsT0 + (qbk & 1) * dstsz;
+      const int qq = (ln & 15) >> 2, pp = ln & 3, g = ln >> 4;
+      auto ds_frag = [&](int k0) -> bf16x8 {
+        const int ka = k0 + 4 * g + qq;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dsT + dst_off(Npad, hh, ka, pp)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dsT + dst_off(Npad, hh, ka + 16, pp)));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+      };
+      // every fragment of the product is requested before the first MFMA (the registers of the main part are free here): the
+      // seven steps then run back to back instead of one LDS round trip each
+      f32x4 dq[NT];
+      bf16x8 kT[nqb][NT], bq[nqb];
+#pragma unroll
+      for (int kb = 0; kb < nqb; ++kb) {
+        bq[kb] = ds_frag(kb * 32);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) kT[kb][j] = cols_lds<DH>(Kimg, kb * 32, kb * 32 + 16, (dt0 + j) * 16, ln);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) dq[j] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int kb = 0; kb < nqb; ++kb)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) dq[j] = MFMA(kT[kb][j], bq[kb], dq[j]);
+      const int q = qbk * 32 + 16 * hh + (ln & 15);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        if (q < N) Vec4<bf16>::store(dqkv + ((int64_t)b * N + q) * rs + h * DH + (dt0 + j) * 16 + 4 * g, dq[j]);
+    };
+    auto dq_part = [&](int qbk, int ln) {
+      if (dq_n == 1) dq_tiles(qbk, dq_hh, dq_dt0, std::integral_constant<int, 1>{}, ln);
+      else if (dq_n == ND) dq_tiles(qbk, dq_hh, dq_dt0, std::integral_constant<int, ND>{}, ln);
+    };
+    const bool owns_keys = key_base < Npad;
+    for (int qbk = 0; qbk < nqb; ++qbk) {
+      if (wave < 4) {
+        if (owns_keys && !(dbg & 0x100)) main_part(qbk);
+        if (qbk > 0 && !(dbg & 0x200)) dq_part(qbk - 1, lane);
+      } else {
+        if (qbk > 0 && !(dbg & 0x200)) dq_part(qbk - 1, lane);
+        if (owns_keys && !(dbg & 0x100)) main_part(qbk);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (qbk == 0) BWD4_STAMP(5);
+      if (qbk == 1) BWD4_STAMP(6);
+    }
+    BWD4_STAMP(7);
+    if (next < nbh) prefetch_regs(next);  // consumed at the top of the next item: the dQ tail and the dK / dV stores cover the latency
+    if (!(dbg & 0x200)) dq_part(nqb - 1, opaque(lane));
+    BWD4_STAMP(8);
+    if (owns_keys) {
+      const int ln = opaque(lane);
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        const int key = key_base + t * 16 + (ln & 15);
+        if (key < N) {
+          bf16* outk = dqkv + ((int64_t)b * N + key) * rs + H * DH + h * DH + 4 * (ln >> 4);
+          bf16* outv = outk + H * DH;
+#pragma unroll
+          for (int dt = 0; dt < ND; ++dt) {
+            Vec4<bf16>::store(outk + dt * 16, dKt[t][dt]);
+            Vec4<bf16>::store(outv + dt * 16, dVt[t][dt]);
+          }
+        }
+      }
+    }
+    BWD4_STAMP(9);
+    if ((dbg & 0x80) && blockIdx.x == 0 && next >= nbh) {
+      __syncthreads();
+      if (threadIdx.x < 120) *reinterpret_cast<unsigned long long*>(dqkv + ((int64_t)b * N + threadIdx.x) * rs + h * DH) = stamps[threadIdx.x];
+    }
+  }
+#undef BWD4_STAMP
+}
+
+template <int DH>
+constexpr size_t bwd4_lds(int Npad) { return (size_t)2 * (3 * Npad * HeadImg<DH>::kRow + 32 + 2 * Npad * 4) + (size_t)2 * (2 * Npad * 32) + 1024; }  // + stamps (testing)
+
 inline size_t bwd2_lds(int N) { return (size_t)2 * ((N + 31) / 32 * 32) * kRowBytes + (size_t)2 * ((N + 31) / 32 * 32) * sizeof(float); }
 
 constexpr int kMaxLds = 160 * 1024;
@@ -936,6 +1233,15 @@ int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const fl
   const int Npad = npad_of(N);
   int ncu = 256;
   { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount; }
+  if (!(g_attn_dbg & (4 | 8 | 32)) && (g_attn_bwd3 & 4) && dh == 48 && Npad == 224) {
+    // persistent prefetching key-owner kernel, one workgroup per CU: 8 waves x 2 key tiles, 193 .. 224 tokens (the MAE decoder: 217)
+    constexpr size_t l4 = bwd4_lds<48>(224);
+    static_assert(l4 <= (size_t)kMaxLds, "bwd4 LDS");
+    const int nbh = B * H, grid = nbh < ncu ? nbh : ncu;
+    if (int rc = set_lds(attn_bwd4_kernel<48, 224>, l4)) return rc;
+    hipLaunchKernelGGL((attn_bwd4_kernel<48, 224>), dim3(grid), dim3(512), l4, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, N, H, (bf16*)dqkv, nbh, g_attn_dbg & 0xF80);
+    return check_hip(hipGetLastError(), "attention_bwd4");
+  }
   if (!(g_attn_dbg & (4 | 8 | 32))) {  // (testing hooks 4 / 8 / 32 select the older kernels)  five-product key-owner kernel for the sequence lengths whose Q / dO / K images leave room for two workgroups per CU
 #define HCT_BWD3(DH_, GS_, KT_, WPS_)                                                                                        \
   do {                                                                                                                 \
