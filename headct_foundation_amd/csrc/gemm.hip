@@ -593,6 +593,118 @@ __device__ __forceinline__ void epilogue_wave64x128_m(const Epilogue& e, const T
 }
 
 
+// Half-width form of the epilogue above for the persistent 256x256 kernel: the wave tile goes through a 4 KiB patch (16 rows
+// x 64 columns of fp32) as 8 sub-tiles (row-tile i, column half h).  The eight patches then fit ONE ring buffer, which leaves
+// the other four to the next tile's first two stage pairs: those are issued before this epilogue, the next main loop starts
+// as soon as they have landed, and the output stores drain under its first K-steps (see the kernel).
+//   bf16 outputs: lane = 8 rows x 8 lanes, 8 consecutive columns (16 B) per lane: one 128-B line per row and instruction;
+//   f32 outputs : lane = 4 rows x 16 lanes, 4 consecutive columns (16 B) per lane: 256 B per row.
+// Same number of vector-memory operations per tile as the full-width form (EpiTraits<MODE>::ops_per_tile).
+template <int MODE>
+__device__ __forceinline__ void tile_bias_halves(const Epilogue& e, int n0, int col0, int lane, int N, TileBias (&b)[2]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    b[h] = TileBias{f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    if (EpiTraits<MODE>::wide) {
+      const int n = n0 + col0 + h * 64 + (lane & 7) * 8;
+      if (e.bias && n < N) {
+        b[h].lo = Vec4<float>::load(e.bias + n);
+        b[h].hi = Vec4<float>::load(e.bias + n + 4);
+      }
+    } else {
+      const int n = n0 + col0 + h * 64 + (lane & 15) * 4;
+      if (e.bias && n < N) b[h].lo = Vec4<float>::load(e.bias + n);
+    }
+  }
+}
+
+template <int MODE, int STORE_POLICY = kNT>
+__device__ __forceinline__ void epilogue_wave64x128_h(const Epilogue& e, const TileBufs& tb, unsigned char* patch, int lane, int m0,
+                                                      int n0, int row0, int col0, int M, int N, const f32x4 (*acc)[8],
+                                                      const TileBias (&bias)[2], f32x4 (&cs)[2][2]) {
+  typedef EpiTraits<MODE> T;
+  asm volatile("" : "+v"(lane));  // opaque per call: see epilogue_wave64x128_m
+  const int frow = lane & 15, fchk = lane >> 4;
+  constexpr int RB = T::wide ? 8 : 4;  // rows per batch (one store instruction)
+  constexpr int NB = 16 / RB;          // batches per sub-tile
+  const int rr = T::wide ? (lane >> 3) : (lane >> 4), cc = T::wide ? (lane & 7) : (lane & 15);
+  const int col = col0 + cc * (T::wide ? 8 : 4);  // in half 0; half 1 is 64 columns further
+  const uint32_t OOB = 0xFFFFFFF0u;
+  int ldc = (int)e.ldc, ldr = (int)e.ldr, ldx = (int)e.ldaux;
+  asm volatile("" : "+s"(ldc), "+s"(ldr), "+s"(ldx));
+  const int rows_left = M - m0 - row0;
+  const uint32_t lane_c = (uint32_t)(rr * ldc + col), lane_r = (uint32_t)(rr * ldr + col), lane_x = (uint32_t)(rr * ldx + col);
+
+  u32x4 ld[2][T::loads ? NB : 1];
+  auto issue_loads = [&](int s) {  // sub-tile s = 2 i + h
+    if (!T::loads) return;
+    const int i = s >> 1, h = s & 1;
+    const bool nok = n0 + col + h * 64 < N;
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int prow = i * 16 + it * RB;
+      const bool ok = nok && prow + rr < rows_left;
+      if (MODE == EPI_RES_F32) ld[s & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(tb.res, ok ? (lane_r + h * 64) * 4u : OOB, (row0 + prow) * ldr * 4, kNT);
+      else ld[s & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(tb.aux, ok ? (lane_x + h * 64) * 2u : OOB, (row0 + prow) * ldx * 2, kNT);
+    }
+  };
+  issue_loads(0);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int i = s >> 1, h = s & 1;
+    const bool nok = n0 + col + h * 64 < N;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4*>(patch + frow * 256 + (((jj * 4 + fchk) ^ frow) << 4)) = acc[i][h * 4 + jj];
+    if (s < 7) issue_loads(s + 1);  // one sub-tile ahead and BEFORE this sub-tile's stores: waiting for it never drains them
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int pr = it * RB + rr;        // row inside the 16-row patch
+      const int prow = i * 16 + it * RB;  // batch's first row inside the wave tile
+      const bool ok = nok && prow + rr < rows_left;
+      if (T::wide) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(patch + pr * 256 + (((2 * cc) ^ pr) << 4));
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(patch + pr * 256 + (((2 * cc + 1) ^ pr) << 4));
+        f32x4 x0 = v0 * e.alpha + bias[h].lo, x1 = v1 * e.alpha + bias[h].hi;
+        const uint32_t vc = ok ? (lane_c + h * 64) * 2u : OOB, vx = ok ? (lane_x + h * 64) * 2u : OOB;
+        const int sc = (row0 + prow) * ldc * 2, sx = (row0 + prow) * ldx * 2;
+        auto pack = [](f32x4 a, f32x4 b) {
+          bf16x8 o = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+          return __builtin_bit_cast(u32x4, o);
+        };
+        if (MODE == EPI_GELU_BF16) {
+          __builtin_amdgcn_raw_buffer_store_b128(pack(x0, x1), tb.aux, vx, sx, kNT);
+          HCT_STORE_GUARD();
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            x0[q] = gelu_fast(x0[q]);
+            x1[q] = gelu_fast(x1[q]);
+          }
+        } else if (MODE == EPI_DGELU_BF16 || MODE == EPI_DGELU_CS) {
+          const bf16x8 t = __builtin_bit_cast(bf16x8, ld[s & 1][it]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            x0[q] *= dgelu_fast((float)t[q]);
+            x1[q] *= dgelu_fast((float)t[4 + q]);
+          }
+          if (MODE == EPI_DGELU_CS) {  // fused bias gradient of the Linear feeding the GELU (column sums of this output)
+            cs[h][0] += ok ? x0 : f32x4{0, 0, 0, 0};
+            cs[h][1] += ok ? x1 : f32x4{0, 0, 0, 0};
+          }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(pack(x0, x1), tb.c, vc, sc, kNT);
+        HCT_STORE_GUARD();
+      } else {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(patch + pr * 256 + ((cc ^ pr) << 4));
+        f32x4 x = v * e.alpha + bias[h].lo;
+        if (MODE == EPI_RES_F32) x += __builtin_bit_cast(f32x4, ld[s & 1][it]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), tb.c, ok ? (lane_c + h * 64) * 4u : OOB, (row0 + prow) * ldc * 4, STORE_POLICY);
+        HCT_STORE_GUARD();
+      }
+    }
+  }
+}
+
+
 // raw buffer descriptor in SGPRs for inline-asm buffer instructions (same 4 words make_buffer_rsrc builds)
 __device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t num_records) {
   const uint64_t pa = (uint64_t)base;
@@ -634,7 +746,17 @@ __device__ uint32_t g_stamp_words = 0;  // capacity of the stamp buffer: the onl
 template <int MODE>
 __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, int K, const bf16* __restrict__ A, int64_t lda,
                                                                  const bf16* __restrict__ B, int64_t ldb, Epilogue e, int ntiles, int stagger) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[163840];  // 5 stages x (A 16K | B 16K); stages 3, 4 double as the epilogue patches
+  __shared__ __attribute__((aligned(16))) unsigned char smem[163840];  // 5 stages x (A 16K | B 16K); stage 4 (generic epilogue: 3 and 4) doubles as the epilogue patches
+  // Specialised epilogues: the next tile's first TWO stage pairs (ring buffers 0 .. 3) are issued before the epilogue, whose
+  // patches are 4 KiB per wave (buffer 4).  The next main loop then waits only for those pairs -- `vmcnt(kEpiOps)`: vector-memory
+  // operations retire in issue order and the epilogue's kEpiOps loads / stores are younger than the pairs -- and the output
+  // stores drain under its first two K-steps.  (With one pair ahead and 8-KiB patches the loop start waited for the stores:
+  // 4 .. 8 us per tile by the in-kernel stamps.)
+#ifndef HCT_NT_TWO_PAIR_MODES  // bit m set: epilogue mode m prefetches two pairs (diagnostic builds override; generic never)
+#define HCT_NT_TWO_PAIR_MODES 0  /* measured: 0x7E (all specialised modes) +0.37 ms per step, 0x2A (the modes without epilogue loads) the same */
+#endif
+  constexpr bool kTwoPairs = MODE != EPI_GENERIC && ((HCT_NT_TWO_PAIR_MODES >> MODE) & 1);
+  constexpr int kEpiOps = EpiTraits<MODE>::ops_per_tile > 63 ? 63 : EpiTraits<MODE>::ops_per_tile;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ntm = (M + 255) >> 8, ntn = (N + 255) >> 8;
   float* const colsum_out = e.colsum_partial;  // by value: indexing through `e` made hipcc keep a copy of the struct in scratch
@@ -727,6 +849,11 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
+  // first odd step of a tile whose first two pairs were waited for at the tile start: nothing has been issued since
+  auto land_first = [&](int t) {
+    if (kTwoPairs && t == 0) __builtin_amdgcn_s_barrier();
+    else land_all();
+  };
   auto land_but_youngest_pair = [&]() {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -746,6 +873,10 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
   int vb = blockIdx.x;
   set_tile(vb);
   stage_pair(0);
+  if (kTwoPairs) {
+    stage_pair(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile: no epilogue behind the pairs to leave in flight
+  }
   while (true) {
     HCT_STAMP(0);
     const int cm0 = m0, cn0 = n0;  // tile being computed (set_tile below moves m0/n0 to the next one)
@@ -757,9 +888,14 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     // the previous tile's epilogue.  Buffers 3 and 4 were that epilogue's patches: once every wave is through with them
     // (barrier) pair (2,3) may go.  Pair (0,1) is older than the epilogue's loads/stores and than pair (2,3) (vmcnt retires
     // in issue order), so allowing the 8 youngest operations to be outstanding means (0,1) has landed.
-    __builtin_amdgcn_s_barrier();
-    stage_pair(2);
-    land_but_youngest_pair();
+    if (kTwoPairs) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kEpiOps) : "memory");  // pairs (0,1), (2,3): older than the previous epilogue's operations
+      __builtin_amdgcn_s_barrier();                                    // ... of every wave; and every wave is done with its patch
+    } else {
+      __builtin_amdgcn_s_barrier();
+      stage_pair(2);
+      land_but_youngest_pair();
+    }
     HCT_STAMP(1);
     rd_a(0, a0);
     rd_b(0, 0, b_lo);
@@ -775,7 +911,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
       mma(1, a0, b_hi);
       rd_b(t + 1, 1, b_hi);
       mma(0, a1, b_lo);
-      land_all();
+      land_first(t);
       stage_pair(t + 4);
       rd_a(t + 2, a0);
       rd_b(t + 2, 0, b_lo);
@@ -789,7 +925,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     mma(1, a0, b_hi);
     rd_b(t + 1, 1, b_hi);
     mma(0, a1, b_lo);
-    land_all();  // pair (nk-2, nk-1)
+    land_first(t);  // pair (nk-2, nk-1)
     rd_a(t + 2, a0);
     rd_b(t + 2, 0, b_lo);
     mma(1, a1, b_hi);
@@ -798,29 +934,36 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     rd_a(t + 3, a1);
     rd_b(t + 3, 0, b_lo);
     mma(1, a0, b_hi);
+    // Bias of this lane's columns: requested here, with nothing else outstanding (every stage has landed) and the a0 fragments
+    // dead, and pinned as resident after the last MFMA group -- part of its L2 round trip runs under the two groups in between.
+    // hipcc cannot count the asm LDS-DMA operations, so a wait it generated for this load after the next tile's prefetch would
+    // wait for that prefetch.
+    TileBias bv = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    TileBias bh[2] = {bv, bv};
+    if (MODE != EPI_GENERIC) tile_bias_halves<MODE>(e, cn0, wn * 128, lane, N, bh);
     rd_b(t + 3, 1, b_hi);
     mma(0, a1, b_lo);
     mma(1, a1, b_hi);
 
     __builtin_amdgcn_s_barrier();  // every wave has its last fragments in registers: the whole ring is free
     HCT_STAMP(2);
-    // Bias of this lane's columns, loaded and pinned as resident BEFORE the prefetch: nothing else is outstanding here, so
-    // the wait costs one L2 round trip.  hipcc cannot count the asm LDS-DMA ops, so a wait it generated for this load
-    // after the prefetch would be a vmcnt(0) -- the epilogue would start only when the whole prefetch has landed.
-    TileBias bv = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
     if (MODE != EPI_GENERIC) {
-      bv = tile_bias<MODE>(e, cn0, wn * 128, lane, N);
-      if (EpiTraits<MODE>::wide) asm volatile("" : "+v"(bv.lo), "+v"(bv.hi));
-      else asm volatile("" : "+v"(bv.lo));
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (EpiTraits<MODE>::wide) asm volatile("" : "+v"(bh[h].lo), "+v"(bh[h].hi));
+        else asm volatile("" : "+v"(bh[h].lo));
+      }
     }
     vb += gridDim.x;
     const bool more = vb < ntiles;
-    if (more) {  // prefetch the next tile's first pair of stages (ring buffers 0, 1) under this tile's epilogue
+    if (more) {  // prefetch the next tile's first pair(s) of stages (ring buffers 0, 1 [, 2, 3]) under this tile's epilogue
       set_tile(vb);
       stage_pair(0);
+      if (kTwoPairs) stage_pair(2);
     }
     {
-      unsigned char* patch = smem + 3 * 32768 + wave * 8192;  // ring buffers 3 and 4: refilled only after the next tile's first barrier
+      // generic: ring buffers 3 and 4 (8 KiB per wave), refilled only after the next tile's first barrier; specialised: buffer 4
+      unsigned char* patch = kTwoPairs ? smem + 4 * 32768 + wave * 4096 : smem + 3 * 32768 + wave * 8192;
       if (MODE == EPI_GENERIC) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) epilogue_tile16x128(e, patch, lane, cm0 + wm * 64 + i * 16, cn0 + wn * 128, M, N, acc[i]);
@@ -830,21 +973,27 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
         tb.c = tile_rsrc(e.C, e.ldc, csz, cm0, cn0, M, N);
         tb.res = tile_rsrc(MODE == EPI_RES_F32 ? (const void*)e.residual : nullptr, e.ldr, 4, cm0, cn0, M, N);
         tb.aux = tile_rsrc((MODE == EPI_GELU_BF16 || MODE == EPI_DGELU_BF16 || MODE == EPI_DGELU_CS) ? e.aux : nullptr, e.ldaux, 2, cm0, cn0, M, N);
-        f32x4 cs0 = {0, 0, 0, 0}, cs1 = {0, 0, 0, 0};
-        epilogue_wave64x128_m<MODE>(e, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv, cs0, cs1);
-        if (MODE == EPI_DGELU_CS) {  // lanes l, l+16, l+32, l+48 hold 4 different rows of the same 8 columns
+        f32x4 cs[2][2] = {{f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}};
+        epilogue_wave64x128_h<MODE>(e, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bh, cs);
+        if (MODE == EPI_DGELU_CS) {  // lanes l, l+8, ..., l+56 hold 8 different rows of the same 8 columns
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            cs0[q] += __shfl_xor(cs0[q], 16, 64);
-            cs0[q] += __shfl_xor(cs0[q], 32, 64);
-            cs1[q] += __shfl_xor(cs1[q], 16, 64);
-            cs1[q] += __shfl_xor(cs1[q], 32, 64);
-          }
-          const int n = cn0 + wn * 128 + (lane & 15) * 8;
-          if (lane < 16 && n < N) {
-            float* dst = colsum_out + ((int64_t)((cm0 >> 8) * 4 + wm)) * N + n;
-            Vec4<float>::store(dst, cs0);
-            Vec4<float>::store(dst + 4, cs1);
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                cs[h][u][q] += __shfl_xor(cs[h][u][q], 8, 64);
+                cs[h][u][q] += __shfl_xor(cs[h][u][q], 16, 64);
+                cs[h][u][q] += __shfl_xor(cs[h][u][q], 32, 64);
+              }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int n = cn0 + wn * 128 + h * 64 + (lane & 7) * 8;
+            if (lane < 8 && n < N) {
+              float* dst = colsum_out + ((int64_t)((cm0 >> 8) * 4 + wm)) * N + n;
+              Vec4<float>::store(dst, cs[h][0]);
+              Vec4<float>::store(dst + 4, cs[h][1]);
+            }
           }
         }
       }

@@ -14,7 +14,7 @@ from test_kernels_gpu import gemm, _rand
 import torch.nn.functional as F
 lib = _lib.load(); cuda = torch.device("cuda")
 tot = {}
-for (M, N, K) in [(165, 768, 768), (512, 512, 256), (2048, 768, 768), (2048, 3072, 768)]:
+for (M, N, K) in [(165, 768, 768), (512, 512, 256), (2048, 768, 768), (2048, 3072, 768), (16384, 1536, 768), (9000, 3072, 256)]:  # the last two: more tiles than CUs (tile hand-over of the persistent kernel)
     A = _rand((M, K), cuda, torch.bfloat16, 1); B = _rand((N, K), cuda, torch.bfloat16, 2, 0.05)
     bias = _rand((N,), cuda, torch.float32, 3); res = _rand((M, N), cuda, torch.float32, 4)
     aux = _rand((M, N), cuda, torch.bfloat16, 7)
