@@ -597,6 +597,58 @@ int fold_rows(const float* partial, int nblk, int D, float* out, hipStream_t s) 
   return check_hip(hipGetLastError(), "fold_rows");
 }
 
+
+// =============================================================================================
+// Separable 3-D Gaussian smoothing (RandGaussianSmoothd of mae3d_transforms, src/data/transforms.py:230-238): one axis per
+// launch, 4 consecutive voxels of the fastest axis per thread, zero padding outside the volume (MONAI's separable_filtering
+// default).  taps [B][3][kGaussTaps]: the sample's centred 1-D kernels (host-computed: erf differences, truncated at 4 sigma ->
+// at most 9 taps for sigma <= 1.06), zero beyond the tail.  Samples whose transform did not fire: the first pass copies them,
+// the other two skip them.
+// =============================================================================================
+constexpr int kGaussTaps = 9;
+__global__ void __launch_bounds__(256) gaussian_pass_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int S, int axis,
+                                                            const float* __restrict__ taps, const unsigned char* __restrict__ apply,
+                                                            int copy_skipped, int64_t n4) {
+  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i4 >= n4) return;
+  const int s4 = S >> 2;
+  const int z4 = (int)(i4 % s4);
+  int64_t t = i4 / s4;
+  const int y = (int)(t % S); t /= S;
+  const int x = (int)(t % S); t /= S;
+  const int b = (int)(t / C);
+  const int64_t base = i4 * 4;
+  if (!apply[b]) {
+    if (copy_skipped) Vec4<float>::store(out + base, Vec4<float>::load(in + base));
+    return;
+  }
+  const float* k = taps + ((int64_t)b * 3 + axis) * kGaussTaps;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (axis == 2) {  // along the contiguous axis: 4 outputs share a 12-voxel window
+    float w[4 + kGaussTaps - 1];
+#pragma unroll
+    for (int j = 0; j < 4 + kGaussTaps - 1; ++j) {
+      const int z = z4 * 4 + j - kGaussTaps / 2;
+      w[j] = (z >= 0 && z < S) ? in[base - z4 * 4 + z] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kGaussTaps; ++u) {
+      const float kv = k[u];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] += kv * w[q + u];
+    }
+  } else {
+    const int pos = axis == 0 ? x : y;
+    const int64_t stride = axis == 0 ? (int64_t)S * S : S;
+#pragma unroll
+    for (int u = 0; u < kGaussTaps; ++u) {
+      const int p = pos + u - kGaussTaps / 2;
+      if (p >= 0 && p < S) acc += Vec4<float>::load(in + base + (int64_t)(u - kGaussTaps / 2) * stride) * k[u];
+    }
+  }
+  Vec4<float>::store(out + base, acc);
+}
+
 }  // namespace hct
 
 // =================================================================================================
@@ -1072,6 +1124,20 @@ int hct_augment_volume(const void* in, int in_dtype, float* out, int B, int C, i
   else if (in_dtype == HCT_BF16) hipLaunchKernelGGL(hct::augment_volume_kernel<hct::bf16>, grid, block, 0, s, (const hct::bf16*)in, out, C, S, flip, shift, n4);
   else hipLaunchKernelGGL(hct::augment_volume_kernel<_Float16>, grid, block, 0, s, (const _Float16*)in, out, C, S, flip, shift, n4);
   HCT_CHECK_LAUNCH("hct_augment_volume");
+  return 0;
+}
+
+int hct_gaussian_smooth3d(const float* in, float* out, float* tmp, int B, int C, int S, const float* taps, const unsigned char* apply,
+                          void* stream) {
+  HCT_REQUIRE(in && out && tmp && taps && apply && B > 0 && C > 0 && S > 0 && S % 4 == 0, "hct_gaussian_smooth3d: bad arguments (S must be a multiple of 4)");
+  HCT_REQUIRE(in != out && in != tmp && out != tmp, "hct_gaussian_smooth3d: in, out and tmp must be three different buffers");
+  const int64_t n4 = (int64_t)B * C * S * S * (S / 4);
+  const dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(hct::gaussian_pass_kernel, grid, block, 0, s, in, out, C, S, 0, taps, apply, 1, n4);                 // first spatial axis
+  hipLaunchKernelGGL(hct::gaussian_pass_kernel, grid, block, 0, s, (const float*)out, tmp, C, S, 1, taps, apply, 0, n4);  // second
+  hipLaunchKernelGGL(hct::gaussian_pass_kernel, grid, block, 0, s, (const float*)tmp, out, C, S, 2, taps, apply, 0, n4);  // third (contiguous)
+  HCT_CHECK_LAUNCH("hct_gaussian_smooth3d");
   return 0;
 }
 

@@ -248,6 +248,14 @@ int hct_hu_window(const void* hu, int in_dtype, void* out, int out_dtype, int B,
                   const float* a_max, void* stream);
 int hct_augment_volume(const void* in, int in_dtype, float* out, int B, int C, int S, const unsigned char* flip,
                        const float* shift, void* stream);
+/* RandGaussianSmoothd of mae3d_transforms(reshape=False) (src/data/transforms.py:230-238; MONAI GaussianSmooth ->
+ * GaussianFilter -> separable_filtering with zero padding): in [B,C,S,S,S] fp32 -> out, one 1-D pass per spatial axis.
+ *   taps  [B][3][9] device fp32: sample b's centred kernel of spatial axis a (0 = slowest), zero beyond its tail; the host
+ *         computes them as MONAI's gaussian_1d(sigma, truncated=4, approx="erf") does (sigma <= 1.06 keeps 9 taps);
+ *   apply [B] device bytes: 0 = the transform did not fire for this sample (out = in).
+ * tmp: scratch of the same size as in/out; the three buffers must differ. */
+int hct_gaussian_smooth3d(const float* in, float* out, float* tmp, int B, int C, int S, const float* taps, const unsigned char* apply,
+                          void* stream);
 
 /* Resume at another resolution: trilinear resize (align_corners = false) of the learnable position table
  * src [extra + g_src^3, D] -> dst [extra + g_dst^3, D], the `extra` leading (class) rows copied unchanged.

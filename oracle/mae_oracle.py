@@ -219,6 +219,38 @@ def augment_volume(x: torch.Tensor, flip: Optional[Sequence[int]] = None, shift:
     return out
 
 
+def gaussian_kernel_1d(sigma: float) -> torch.Tensor:
+    """MONAI `gaussian_1d(sigma, truncated=4.0, approx="erf", normalize=False)` -- the kernel GaussianFilter builds for
+    GaussianSmooth / RandGaussianSmoothd (src/data/transforms.py:230-238): tail = int(max(4 sigma, 0.5) + 0.5) taps either side,
+    w(x) = 0.5 (erf(t (x + 0.5)) - erf(t (x - 0.5))) with t = 0.70710678 / |sigma|, clamped at 0; fp32.  (Stated from knowledge
+    of MONAI 1.2 / 1.3: MONAI is not installed here, so parity with MONAI itself is unpinned.)"""
+    sg = torch.tensor(float(sigma), dtype=torch.float32)
+    tail = int(max(float(sg) * 4.0, 0.5) + 0.5)
+    x = torch.arange(-tail, tail + 1, dtype=torch.float32)
+    t = 0.70710678 / torch.abs(sg)
+    return (0.5 * ((t * (x + 0.5)).erf() - (t * (x - 0.5)).erf())).clamp(min=0)
+
+
+def gaussian_smooth3d(x: torch.Tensor, sigma: Sequence[Sequence[float]], apply: Optional[Sequence[bool]] = None) -> torch.Tensor:
+    """RandGaussianSmoothd with its draws made explicit: sample b of x [B, C, S0, S1, S2] is filtered along each spatial axis a with
+    gaussian_kernel_1d(sigma[b][a]) under zero padding (MONAI separable_filtering, mode "zeros") when apply[b], else left as is."""
+    out = x.to(torch.float32).clone()
+    for b in range(x.shape[0]):
+        if apply is not None and not apply[b]:
+            continue
+        v = out[b].unsqueeze(0)  # [1, C, S0, S1, S2]
+        C = v.shape[1]
+        for a in range(3):
+            k = gaussian_kernel_1d(sigma[b][a])
+            shape = [1, 1, 1, 1, 1]
+            shape[2 + a] = k.numel()
+            pad = [0, 0, 0]
+            pad[a] = (k.numel() - 1) // 2
+            v = F.conv3d(v, k.reshape(shape).repeat(C, 1, 1, 1, 1), padding=pad, groups=C)
+        out[b] = v[0]
+    return out
+
+
 def hu_window(hu: torch.Tensor, in_channels: int = 1) -> torch.Tensor:
     """Windowing step of loading_transforms (src/data/transforms.py:108-133): one channel = ScaleIntensityRanged(a_min 40-150,
     a_max 40+150, b 0..1, clip); three = MultipleWindowScaleStack (:8-36) over (centre, width) (40,80), (80,200), (600,2800)

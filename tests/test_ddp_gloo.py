@@ -106,3 +106,65 @@ def test_plan_stage_ranges_are_contiguous_and_descending(lib):
         assert prev_begin == 0
     finally:
         lib.hct_mae_plan_destroy(h)
+
+
+class _FakeHead:
+    """The DINO head's contract with DinoDataParallel: flat parameter / gradient buffers."""
+
+    def __init__(self, n, rank):
+        self._flat = torch.full((n,), float(rank + 1))
+        self._flat_grad = torch.zeros(n)
+        self.marked = 0
+
+    def mark_weights_updated(self, plain_bf16_fresh=False):
+        self.marked += 1
+
+
+class _FakeMultiCrop(torch.nn.Module):
+    def __init__(self, backbone, head):
+        super().__init__()
+        self.backbone = backbone
+        self.head = head
+
+    def forward(self, x):
+        return x
+
+
+def _dino_worker(rank, world, port, total, ranges, n_head):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from headct_foundation_amd.dino import DinoDataParallel
+        backbone = _FakeFlatModel(total, ranges)
+        backbone._flat += float(rank + 1)
+        head = _FakeHead(n_head, rank)
+        ddp = DinoDataParallel(_FakeMultiCrop(backbone, head), bucket_cap_mb=0.004)
+        # rank 0's backbone and head parameters everywhere
+        assert torch.all(backbone._flat == 1.0) and backbone.marked == 1
+        assert torch.all(head._flat == 1.0) and head.marked == 1
+        assert ddp.module.head is head and ddp(3) == 3
+        for _ in range(2):  # one iteration of the engine: backbone buckets during its backward, the head's gradient right after
+            backbone._flat_grad.zero_()
+            backbone.backward(rank)
+            head._flat_grad = (torch.arange(n_head, dtype=torch.float32) + 1.0) * (rank + 1)
+            ddp.reduce_head_gradients()
+            mean_factor = sum(r + 1 for r in range(world)) / world
+            assert torch.allclose(backbone._flat_grad, (torch.arange(total, dtype=torch.float32) + 1.0) * mean_factor)
+            assert torch.allclose(head._flat_grad, (torch.arange(n_head, dtype=torch.float32) + 1.0) * mean_factor)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dino_data_parallel_world2():
+    """DINO (config #5) over two ranks: backbone gradient in buckets through its staged backward, head gradient in one all-reduce,
+    both averaged; rank 0's parameters broadcast at construction (engine_pretrain_dino.train_one_epoch's data-parallel calls)."""
+    total = 4 * 1024
+    ranges = [(3072, 4096), (2048, 3072), (1024, 2048), (0, 1024)]
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_dino_worker, args=(r, 2, port, total, ranges, 777)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0

@@ -358,6 +358,42 @@ def test_augment_volume_vs_oracle(lib, cuda, dtype):
     assert float(sft.abs().max()) <= 0.1
 
 
+def test_gaussian_smooth_vs_oracle(lib, cuda):
+    """hct_gaussian_smooth3d / DeviceAugment(smooth_prob) vs the oracle's restatement of RandGaussianSmoothd (transforms.py:230-238):
+    per-sample, per-axis sigmas in [0.5, 1], zero padding, samples whose transform did not fire left bit-identical.  Parity with
+    MONAI's GaussianFilter itself is unpinned (MONAI is not installed); against the oracle 2e-6 (sums of <= 9 fp32 products per pass)."""
+    from oracle import mae_oracle as O
+    from headct_foundation_amd.data import DeviceAugment, gaussian_smooth, gaussian_taps
+    B, Cc, S = 5, 2, 16
+    x = _rand((B, Cc, S, S, S), cuda, torch.float32, 31).abs()
+    sigma = torch.tensor([[0.5, 0.75, 1.0], [1.0, 1.0, 1.0], [0.6, 0.5, 0.9], [0.5, 0.5, 0.5], [0.99, 0.51, 0.7]])
+    fire = torch.tensor([True, True, False, True, True])
+    got = gaussian_smooth(x, sigma, fire)
+    want = O.gaussian_smooth3d(x.cpu(), sigma.tolist(), fire.tolist())
+    assert torch.equal(got[2].cpu(), x[2].cpu())
+    assert float((got.cpu() - want).abs().max()) < 2e-6
+    # the host taps are the oracle's kernels, zero beyond the tail
+    taps = gaussian_taps(sigma)
+    for b in range(B):
+        for a in range(3):
+            k = O.gaussian_kernel_1d(float(sigma[b, a]))
+            pad = (9 - k.numel()) // 2
+            assert torch.equal(taps[b, a, pad:9 - pad], k) and float(taps[b, a, :pad].abs().sum() + taps[b, a, 9 - pad:].abs().sum()) == 0.0
+    # a constant volume stays constant away from the borders (the erf kernel sums to 1 within 1e-4)
+    c = gaussian_smooth(torch.full((1, 1, S, S, S), 0.7, device=cuda), torch.tensor([[1.0, 1.0, 1.0]]))
+    half = float(O.gaussian_kernel_1d(1.0)[4:].sum())  # zero padding: the corner keeps the in-volume half of each 1-D kernel
+    assert float((c[0, 0, 4:-4, 4:-4, 4:-4] - 0.7).abs().max()) < 1e-4 and abs(float(c[0, 0, 0, 0, 0]) - 0.7 * half ** 3) < 1e-6
+    # inside DeviceAugment: same draws -> same volumes as the oracle's chain
+    aug = DeviceAugment(flip_prob=0.5, shift_offsets=0.1, shift_prob=0.5, seed=2, smooth_prob=0.6)  # seed 2: samples 1, 3, 4 fire
+    y = aug(x.half())
+    f, sft, fired, sg = aug.last_draw
+    ref = O.gaussian_smooth3d(O.augment_volume(x.half().cpu(), f.tolist(), sft.tolist()), sg.tolist(), fired.tolist())
+    assert bool(fired.any()) and not bool(fired.all())
+    assert float((y.cpu() - ref).abs().max()) < 2e-6
+    with pytest.raises(ValueError):
+        gaussian_taps(torch.tensor([1.5]))
+
+
 @pytest.mark.parametrize("channels", [1, 3])
 def test_hu_window_vs_oracle(lib, cuda, channels):
     """HU windowing of loading_transforms (transforms.py:108-133) on the device: bit-equal to the oracle's fp32 restatement, and

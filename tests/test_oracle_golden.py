@@ -253,3 +253,27 @@ def test_dino_oracle_vs_reference_fixture():
     assert np.array_equal(D.cosine_scheduler(S["base"], S["final"], S["epochs"], S["niter"], S["warmup_epochs"], S["start"]), np.array(S["values"]))
     from headct_foundation_amd.dino import wd_cosine_scheduler
     assert np.array_equal(wd_cosine_scheduler(S["base"], S["final"], S["epochs"], S["niter"], S["warmup_epochs"], S["start"]), np.array(S["values"]))
+
+
+def test_gaussian_smoothing_restatement_properties():
+    """RandGaussianSmoothd restatement (transforms.py:230-238; MONAI absent, so pinned by properties only): kernel length and mass
+    per sigma, separability (three 1-D passes == one dense 3-D correlation with the outer-product kernel), zero padding, samples
+    that did not fire untouched."""
+    from oracle import mae_oracle as O
+    for sg, taps in ((0.5, 5), (0.62, 5), (0.63, 7), (0.87, 7), (0.88, 9), (1.0, 9)):
+        k = O.gaussian_kernel_1d(sg)
+        assert k.numel() == taps and abs(float(k.sum()) - 1.0) < 1e-4 and torch.equal(k, k.flip(0)) and float(k.min()) >= 0
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 2, 8, 8, 8, generator=g)
+    sigma = [[0.5, 0.8, 1.0], [0.7, 0.7, 0.7]]
+    y = O.gaussian_smooth3d(x, sigma, [True, False])
+    assert torch.equal(y[1], x[1])
+    kx, ky, kz = (O.gaussian_kernel_1d(s) for s in sigma[0])
+    dense = torch.einsum("i,j,k->ijk", kx, ky, kz)
+    pad = [(n - 1) // 2 for n in dense.shape]
+    want = torch.nn.functional.conv3d(x[:1].reshape(2, 1, 8, 8, 8), dense[None, None], padding=pad).reshape(2, 8, 8, 8)
+    assert float((y[0] - want).abs().max()) < 1e-6
+    # zero padding: the corner voxel of a constant volume keeps only the in-volume half of each 1-D kernel
+    c = O.gaussian_smooth3d(torch.ones(1, 1, 12, 12, 12), [[1.0, 1.0, 1.0]])
+    half = float(O.gaussian_kernel_1d(1.0)[4:].sum())
+    assert abs(float(c[0, 0, 0, 0, 0]) - half ** 3) < 1e-6 and abs(float(c[0, 0, 6, 6, 6]) - 1.0) < 1e-4
