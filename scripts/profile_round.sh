@@ -3,10 +3,12 @@
 #   bash scripts/profile_round.sh r02
 set -e
 TAG=${1:-r02}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/${TAG}_prof
+cd /tmp
+OUT=$ROOT/gpurun_out/${TAG}_prof
 mkdir -p $OUT
-BENCH="python3 $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof"
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $BENCH > $OUT/kt.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/mfma -o mfma -- $BENCH > $OUT/mfma.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $OUT/valu -o valu -- $BENCH > $OUT/valu.log 2>&1 || true
@@ -14,5 +16,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o write -- $BENCH > $OUT/write.log 2>&1
 find $OUT -name "*.csv" | xargs ls -la
 # keep what merges back small: the per-dispatch traces are summarised here
-python3 $PWD/scripts/summarize_round.py $OUT $PWD/gpurun_out/${TAG}_summary.json || true
+python3 $ROOT/scripts/summarize_round.py $OUT $ROOT/gpurun_out/${TAG}_summary.json || true
+python3 $ROOT/scripts/summarize_pmc.py $(find $OUT/fetch -name "*counter_collection.csv" | head -n 1) $(find $OUT/write -name "*counter_collection.csv" | head -n 1) $ROOT/gpurun_out/${TAG}_pmc_nt256.json || true
+cp $(find $OUT/kt -name "*kernel_stats.csv" | head -n 1) $ROOT/gpurun_out/${TAG}_kernel_stats.csv || true
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
