@@ -18,7 +18,7 @@
 
 namespace hct {
 
-int g_attn_bwd3 = 6;  // which shapes use the key-owner five-product backward: bit0 head dim 48 (<= 256 tokens, bwd3), bit1 head dim 64 (<= 192 tokens, bwd3), bit2 head dim 48 with 193 .. 224 tokens (persistent bwd4)
+int g_attn_bwd3 = 6;  // bit3 (opt-in: measured equal to the kernel it would replace, 116 vs 117 us): persistent forward (fwd4) for head dim 48 with 193 .. 224 tokens.  Which shapes use the key-owner five-product backward: bit0 head dim 48 (<= 256 tokens, bwd3), bit1 head dim 64 (<= 192 tokens, bwd3), bit2 head dim 48 with 193 .. 224 tokens (persistent bwd4)
 int g_attn_dbg = 0;  // timing experiments on the backward kernel: bit0 skip key-owner pass, bit1 skip query-owner pass
 
 namespace {
@@ -895,6 +895,7 @@ inline size_t bwd3_lds(int Npad) { return (size_t)3 * Npad * HeadImg<DH>::kRow +
 //     VALU-heavy S / P / dS part while its partner streams the MFMA-only dQ product.
 // The operand stream is inline-asm LDS-DMA (hipcc would drain vmcnt before the first LDS read behind a builtin DMA).
 typedef __attribute__((ext_vector_type(4))) int attn_i32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2a;
 __device__ __forceinline__ attn_i32x4 attn_srd(const void* base, int64_t bytes) {
   const uint64_t pa = (uint64_t)base;
   const uint32_t rec = bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (bytes < 0 ? 0u : (uint32_t)bytes);
@@ -1173,6 +1174,134 @@ __global__ void __launch_bounds__(512, 2) attn_bwd4_kernel(const bf16* __restric
 #undef BWD4_STAMP
 }
 
+// ============================================================================================================
+// Forward, PERSISTENT form (fwd4) for the decoder shape (head dim 48, 193 .. 224 tokens): the structure of bwd4 without any
+// exchange between waves.  One 16-wave workgroup per CU walks the (batch, head) items; the next item's Q / K / V images land by
+// LDS-DMA in the other LDS buffer while the current one is computed; one barrier per item.  A wave owns one 16-query tile, keeps
+// the whole score row in registers (S^T = K Q^T: 14 key tiles = 56 registers), takes the row maximum and sum across its four
+// 16-lane groups, and feeds P as the B operand of O^T = V^T P.  Four waves per SIMD (128 registers each) drift apart between two
+// item barriers, so one wave's softmax VALU runs under another's MFMAs -- with 8 waves of two tiles each (256 registers, half
+// the K / V fragment reads) the two waves of a SIMD stayed in step and the kernel was slower than the one it replaces (128 vs
+// 116 us).  MEASURED (scripts/dbg/attn_fwd4.py, B = 256, N = 217, H = 16): 117 us against 116 us for attn_fwd_row_kernel, so it
+// is NOT the default (g_attn_bwd3 bit 3 selects it); image traffic alone 55 us, compute + stores on stale images 78 us: the two
+// overlap only partly, and the compute part is VALU-issue bound (per 16-query tile 290 VALU of which 56 v_exp_f32, 49 MFMA).  The O / lse stores are buffer stores with out-of-range offsets on masked lanes, so that every wave issues the same
+// number of them and the next item's "images have landed" wait can leave exactly those in flight.
+template <int DH, int Npad>
+__global__ void __launch_bounds__(1024) attn_fwd4_kernel(const bf16* __restrict__ qkv, int N, int H, bf16* __restrict__ o,
+                                                         float* __restrict__ lse, int nbh, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ROW = HeadImg<DH>::kRow, CH = HeadImg<DH>::kChunks, ND = DH / 16, NT = Npad / 16, NW = 16;
+  constexpr int img = Npad * ROW;
+  constexpr int bufsz = 3 * img;  // Q | K | V (the streamed K fragment of the last row reads on into V: finite bf16)
+  constexpr int pieces = Npad * CH / 64, MAXP = (pieces + NW - 1) / NW;
+  static_assert(NT <= NW, "fwd4: one query tile per wave");
+  const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4;
+  const int64_t rs = (int64_t)3 * H * DH, os = (int64_t)H * DH;
+  const float scale = rsqrtf((float)DH) * 1.44269504088896340736f;  // softmax in base 2
+  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  auto item_bh = [&](int item) {
+    const int xcd = item & 7, q = nbh >> 3, r = nbh & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (item >> 3);
+  };
+  auto prefetch_images = [&](int item, int buf) {
+    const int bh = item_bh(item), b = bh / H, h = bh - b * H;
+    const bf16* qb = qkv + (int64_t)b * N * rs + h * DH;
+    const int64_t bytes = ((int64_t)(N - 1) * rs + DH) * 2;
+    const attn_i32x4 rq = attn_srd(qb, bytes), rk = attn_srd(qb + H * DH, bytes), rv = attn_srd(qb + 2 * H * DH, bytes);
+    const uint32_t base = lds0 + buf * bufsz;
+    const int ln = opaque(lane);
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int p = wave + NW * i;
+      if (p < pieces) {
+        const int ci = p * 64 + ln, row = ci / CH, slot = ci - row * CH;
+        const uint32_t src = (uint32_t)((DH == 48 ? slot : (slot ^ ((row >> 1) & 7))) * 16);
+        const uint32_t vq = (uint32_t)row * (uint32_t)(rs * 2) + src;
+        attn_dma16(rq, base + p * 1024, vq);
+        attn_dma16(rk, base + img + p * 1024, vq);
+        attn_dma16(rv, base + 2 * img + p * 1024, vq);
+      }
+    }
+  };
+  int item = blockIdx.x;
+  if (item >= nbh) return;
+  prefetch_images(item, 0);
+  const bool has_rows = wave < NT;    // (Npad = 224: waves 14 and 15 own no queries; they still move their share of the images)
+  constexpr int kStores = ND + 1;     // buffer stores a query-owning wave issues per item
+  for (int it = 0; item < nbh; item += gridDim.x, ++it) {
+    const int cur = it & 1;
+    const unsigned char* Qimg = smem + cur * bufsz;
+    const unsigned char* Kimg = Qimg + img;
+    const unsigned char* Vimg = Kimg + img;
+    const int bh = item_bh(item), b = bh / H, h = bh - b * H;
+    // images landed: the previous item's stores (younger than this item's DMA pieces) may stay in flight
+    if (it == 0 || !has_rows) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const int next = item + gridDim.x;
+    if (next < nbh && !(dbg & 0x200)) prefetch_images(next, cur ^ 1);  // (0x200, testing: compute on stale images)
+    if (has_rows && !(dbg & 0x100)) {  // (0x100, testing: image traffic only)
+      const int q0 = wave * 16;
+      const RowFrag<DH> qf = rows_lds<DH>(Qimg, q0, lane, true);
+      f32x4 st[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) st[t] = mma_rows<DH>(rows_lds<DH>(Kimg, t * 16, lane, false), qf, f32x4{0, 0, 0, 0});  // S^T[key = 16 t + 4 g + r][q = lane & 15]
+      float m = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (t * 16 + 15 >= 192 && t * 16 + 4 * g + r >= N) st[t][r] = -INFINITY;  // (only the tiles that can hold keys >= N: N > 192)
+          m = fmaxf(m, st[t][r]);
+        }
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      const float mx = m * scale;
+      float ps = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          st[t][r] = __builtin_amdgcn_exp2f(fmaf(st[t][r], scale, -mx));
+          ps += st[t][r];
+        }
+      ps += __shfl_xor(ps, 16, 64);
+      ps += __shfl_xor(ps, 32, 64);
+      f32x4 oacc[ND];
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) oacc[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int s2 = 0; s2 < NT / 2; ++s2) {
+        const bf16x8 pb = pack8(st[2 * s2], st[2 * s2 + 1]);
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) oacc[dt] = MFMA(cols_lds<DH>(Vimg, s2 * 32, s2 * 32 + 16, dt * 16, lane), pb, oacc[dt]);  // O^T[d = 16 dt + 4 g + r][q]
+      }
+      // stores: O [B, N, H dh] bf16 (4 consecutive d per lane) and lse [B, H, N] in natural-log units; masked lanes out of range
+      const int ln = opaque(lane);
+      __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(o + (int64_t)b * N * os + h * DH), 0,
+                                                                    (uint32_t)(((int64_t)(N - 1) * os + DH) * 2), 0x00020000);
+      __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lse + (int64_t)bh * N), 0, (uint32_t)(N * 4), 0x00020000);
+      const int q = q0 + (ln & 15);
+      const float inv = 1.0f / ps;
+      const uint32_t voff = q < N ? (uint32_t)(q * (int)os * 2 + (ln >> 4) * 8) : 0xFFFFFFF0u;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        const f32x4 v = oacc[dt] * inv;
+        const bf16x4 ob = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        // d-tile in the scalar offset: it is not part of the range check, so a masked lane's offset cannot wrap back into the buffer
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2a, ob), ro, voff, dt * 32, 0);
+      }
+      const float l = (mx + __builtin_amdgcn_logf(ps)) * 0.69314718055994530942f;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, l), rl, (q < N && (ln >> 4) == 0) ? (uint32_t)(q * 4) : 0xFFFFFFF0u, 0, 0);
+    }
+  }
+}
+
+template <int DH>
+constexpr size_t fwd4_lds(int Npad) { return (size_t)2 * (3 * Npad * HeadImg<DH>::kRow); }
+
 template <int DH>
 constexpr size_t bwd4_lds(int Npad) { return (size_t)2 * (3 * Npad * HeadImg<DH>::kRow + 32 + 2 * Npad * 4) + (size_t)2 * (2 * Npad * 32) + 1024; }  // + stamps (testing)
 
@@ -1209,9 +1338,27 @@ static int launch_fwd_row(const void* qkv, int B, int N, int H, void* o, float* 
 
 int g_attn_row = 1;  // testing hook: 0 = always the online-softmax kernel
 
+static int num_cus_cached() {  // (hipGetDeviceProperties costs tens of microseconds of host time per call)
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+
 int attention_fwd_mfma(const void* qkv, int B, int N, int H, int dh, void* o, float* lse, hipStream_t s) {
   const int Npad = npad_of(N);
   const size_t lds = fwd_lds(N);
+  if (g_attn_row && (g_attn_bwd3 & 8) && dh == 48 && Npad == 224) {  // persistent prefetching kernel for the decoder shape
+    constexpr size_t l4 = fwd4_lds<48>(224);
+    static_assert(l4 <= (size_t)kMaxLds, "fwd4 LDS");
+    const int nbh = B * H, ncu = num_cus_cached(), grid = nbh < ncu ? nbh : ncu;
+    if (int rc = set_lds(attn_fwd4_kernel<48, 224>, l4)) return rc;
+    hipLaunchKernelGGL((attn_fwd4_kernel<48, 224>), dim3(grid), dim3(1024), l4, s, (const bf16*)qkv, N, H, (bf16*)o, lse, nbh, g_attn_dbg & 0xF00);
+    return check_hip(hipGetLastError(), "attention_fwd4");
+  }
   if (g_attn_row) {  // full-row kernels for the MAE token counts (<= 64, <= 160, <= 224, <= 288 keys)
     const int nt = Npad / 16;
 #define HCT_ROW(DH_, NT_) if (dh == DH_ && nt <= NT_) return launch_fwd_row<DH_, NT_>(qkv, B, N, H, o, lse, s)
@@ -1231,8 +1378,7 @@ int attention_fwd_mfma(const void* qkv, int B, int N, int H, int dh, void* o, fl
 int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const float* lse, int B, int N, int H, int dh,
                        void* dqkv, hipStream_t s) {
   const int Npad = npad_of(N);
-  int ncu = 256;
-  { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount; }
+  const int ncu = num_cus_cached();
   if (!(g_attn_dbg & (4 | 8 | 32)) && (g_attn_bwd3 & 4) && dh == 48 && Npad == 224) {
     // persistent prefetching key-owner kernel, one workgroup per CU: 8 waves x 2 key tiles, 193 .. 224 tokens (the MAE decoder: 217)
     constexpr size_t l4 = bwd4_lds<48>(224);

@@ -25,6 +25,7 @@ HOOKS = {
     "bwd3enc": (lambda: lib.hct_debug_force_simple_attention(100006), lambda: lib.hct_debug_force_simple_attention(100004)),  # on = key-owner backward for the encoder
     "bwd3off": (lambda: lib.hct_debug_force_simple_attention(42), lambda: lib.hct_debug_force_simple_attention(10)),  # on = two-phase backward everywhere
     "bwd4off": (lambda: lib.hct_debug_force_simple_attention(100002), lambda: lib.hct_debug_force_simple_attention(100006)),  # on = two-phase backward for the decoder instead of the persistent key-owner kernel
+    "fwd4": (lambda: lib.hct_debug_force_simple_attention(100014), lambda: lib.hct_debug_force_simple_attention(100006)),  # on = persistent forward for the decoder
     "stagger2": (lambda: lib.hct_debug_set_gemm_stagger(2), lambda: lib.hct_debug_set_gemm_stagger(-1)),
     "stagger4": (lambda: lib.hct_debug_set_gemm_stagger(4), lambda: lib.hct_debug_set_gemm_stagger(-1)),
     "none": (lambda: None, lambda: None),
