@@ -212,9 +212,10 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma_kernel(const bf16* __restri
 // ============================================================================================================
 // Forward, full-row form for short sequences (NT = Npad/16 key tiles known at compile time): per 16-query tile all
 // 2*NT Q.K^T MFMAs issue back-to-back into NT accumulators, ONE softmax over the whole row (max / exp / sum: two
-// cross-lane steps in total instead of per 32-key step), then the (NT/2)*ND P.V MFMAs.  8 waves per (batch, head).
-template <int DH, int NT>
-__global__ void __launch_bounds__(512) attn_fwd_row_kernel(const bf16* __restrict__ qkv, int N, int H, bf16* __restrict__ o,
+// cross-lane steps in total instead of per 32-key step), then the (NT/2)*ND P.V MFMAs.
+// NW waves per (batch, head): 8, or 4 when there are at most 4 query tiles (the encoder's 55 tokens), so that every wave owns rows.
+template <int DH, int NT, int NW = (NT <= 4 ? 4 : 8)>
+__global__ void __launch_bounds__(NW * 64) attn_fwd_row_kernel(const bf16* __restrict__ qkv, int N, int H, bf16* __restrict__ o,
                                                            float* __restrict__ lse) {
   constexpr int Npad = NT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -226,14 +227,14 @@ __global__ void __launch_bounds__(512) attn_fwd_row_kernel(const bf16* __restric
   const bf16* qb = qkv + (int64_t)b * N * rs + h * DH;
   const int g = lane >> 4;
   constexpr int ND = DH / 16;
-  constexpr int MAXT = (NT + 7) / 8;  // query tiles per wave
+  constexpr int MAXT = (NT + NW - 1) / NW;  // query tiles per wave
   const int nqt = (N + 15) >> 4;
   // Q fragments of all of this wave's query tiles are fetched up front, together with the K/V images, so their HBM
   // latency is paid once per workgroup instead of once per query tile
   bf16x8 qall[MAXT][2];
 #pragma unroll
   for (int it = 0; it < MAXT; ++it) {
-    const int q = (wave + it * 8) * 16 + (lane & 15);
+    const int q = (wave + it * NW) * 16 + (lane & 15);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int d = ks * 32 + 8 * g;
@@ -242,13 +243,13 @@ __global__ void __launch_bounds__(512) attn_fwd_row_kernel(const bf16* __restric
       qall[it][ks] = v;
     }
   }
-  load_image<DH>(Kimg, qb + H * DH, rs, N, Npad, 512);
-  load_image<DH>(Vimg, qb + 2 * H * DH, rs, N, Npad, 512);
+  load_image<DH>(Kimg, qb + H * DH, rs, N, Npad, NW * 64);
+  load_image<DH>(Vimg, qb + 2 * H * DH, rs, N, Npad, NW * 64);
   __syncthreads();
   const float scale = rsqrtf((float)DH) * 1.44269504088896340736f;  // fold log2(e): softmax in base 2
 #pragma unroll
   for (int it = 0; it < MAXT; ++it) {
-    const int qt = wave + it * 8;
+    const int qt = wave + it * NW;
     if (qt >= nqt) break;
     const int q = qt * 16 + (lane & 15);
     bf16x8 qf[2] = {qall[it][0], qall[it][1]};
@@ -1091,6 +1092,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd4_kernel(const bf16* __restric
           dVt[t][dt] = MFMA(dT[dt], pa, dVt[t][dt]);   // dV^T[d][key] += dO^T.P
           dKt[t][dt] = MFMA(qT[dt], dsa, dKt[t][dt]);  // dK^T[d][key] += Q^T.dS
         }
+#ifdef HCT_BWD4_SEQ_TILES  // (experiment) keep the two key tiles strictly one after the other in the instruction stream
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     };
     // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] of block qbk, tiles (hh, dt0 .. dt0 + NT - 1): the dS^T fragment is shared
@@ -1332,7 +1336,7 @@ template <int DH, int NT>
 static int launch_fwd_row(const void* qkv, int B, int N, int H, void* o, float* lse, hipStream_t s) {
   const size_t lds = (size_t)2 * NT * 16 * kRowBytes;
   if (int rc = set_lds(attn_fwd_row_kernel<DH, NT>, lds)) return rc;
-  hipLaunchKernelGGL((attn_fwd_row_kernel<DH, NT>), dim3(B * H), dim3(512), lds, s, (const bf16*)qkv, N, H, (bf16*)o, lse);
+  hipLaunchKernelGGL((attn_fwd_row_kernel<DH, NT>), dim3(B * H), dim3(NT <= 4 ? 256 : 512), lds, s, (const bf16*)qkv, N, H, (bf16*)o, lse);
   return check_hip(hipGetLastError(), "attention_fwd_row");
 }
 

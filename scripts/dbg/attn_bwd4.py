@@ -4,6 +4,8 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from headct_foundation_amd import _lib
+if os.environ.get('HCT_LIB_TAG'):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"libheadct_hip_{os.environ['HCT_LIB_TAG']}.so")
 lib = _lib.load(); dev = torch.device("cuda"); st = torch.cuda.current_stream().cuda_stream
 
 
