@@ -18,7 +18,7 @@
 
 namespace hct {
 
-int g_attn_bwd3 = 6;  // bit3 (opt-in: measured equal to the kernel it would replace, 116 vs 117 us): persistent forward (fwd4) for head dim 48 with 193 .. 224 tokens.  Which shapes use the key-owner five-product backward: bit0 head dim 48 (<= 256 tokens, bwd3), bit1 head dim 64 (<= 192 tokens, bwd3), bit2 head dim 48 with 193 .. 224 tokens (persistent bwd4)
+int g_attn_bwd3 = 22;  // bit4: bwd4 as 16 waves x one key tile (128 registers, four waves per SIMD: 287 vs 305 us, -0.09 ms per step) instead of 8 x two.  bit3 (opt-in: measured equal to the kernel it would replace, 116 vs 117 us): persistent forward (fwd4) for head dim 48 with 193 .. 224 tokens.  Which shapes use the key-owner five-product backward: bit0 head dim 48 (<= 256 tokens, bwd3), bit1 head dim 64 (<= 192 tokens, bwd3), bit2 head dim 48 with 193 .. 224 tokens (persistent bwd4)
 int g_attn_dbg = 0;  // timing experiments on the backward kernel: bit0 skip key-owner pass, bit1 skip query-owner pass
 
 namespace {
@@ -907,26 +907,25 @@ __device__ __forceinline__ void attn_dma16(attn_i32x4 rsrc, uint32_t lds_base, u
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc) : "memory", "m0");
 }
 
-template <int DH, int Npad>
-__global__ void __launch_bounds__(512, 2) attn_bwd4_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+template <int DH, int Npad, int KT = 2>
+__global__ void __launch_bounds__(1024 / KT, 2 * 2 / KT) attn_bwd4_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                            const bf16* __restrict__ d_o, const float* __restrict__ lse, int N, int H,
                                                            bf16* __restrict__ dqkv, int nbh, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int ROW = HeadImg<DH>::kRow, CH = HeadImg<DH>::kChunks, ND = DH / 16, KT = 2;
+  constexpr int ROW = HeadImg<DH>::kRow, CH = HeadImg<DH>::kChunks, ND = DH / 16, NW = 16 / KT;  // KT key tiles per wave, NW waves
   constexpr int img = Npad * ROW;                       // one image
   constexpr int bufsz = 3 * img + 32 + 2 * Npad * 4;    // Q | dO | K | 32 zero bytes (the streamed K fragment of the last row reads them) | lse | delta
   unsigned char* const dsT0 = smem + 2 * bufsz;     // dS^T, two buffers of 2 * Npad * 32
   constexpr int dstsz = 2 * Npad * 32;
   const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = lane >> 4;
   const int64_t rs = (int64_t)3 * H * DH, os = (int64_t)H * DH;
   const float scale = rsqrtf((float)DH);
   const float scale2 = scale * 1.44269504088896340736f;
   const int key_base = wave * (KT * 16);
   constexpr int nqb = Npad >> 5;
   constexpr int pieces = Npad * CH / 64;                // 1-KiB DMA pieces per image
-  constexpr int MAXP = 3;                           // ceil(pieces / 8) for Npad <= 256
+  constexpr int MAXP = (pieces + NW - 1) / NW;
   // Per-lane offsets used only between two items (DMA sources, register prefetch, dK / dV rows) are recomputed there from an
   // opaque copy of the lane id: hoisted out of the item loop they were spilled to scratch, and every reload is a vector-memory
   // operation whose wait also drains the stores in flight.
@@ -943,7 +942,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd4_kernel(const bf16* __restric
   // VALU-heavy P / dS part) and the fragment reads after a barrier come in two bursts.  With 14 key tiles (Npad = 224) wave 7
   // owns no keys and takes one query half whole.
   int dq_hh, dq_dt0, dq_n;
-  if (key_base >= Npad) { dq_hh = 0; dq_dt0 = 0; dq_n = ND; }
+  if (KT == 1) {  // 16 waves, 14 key tiles: the two waves without keys take one query half each
+    dq_hh = wave - (NW - 2); dq_dt0 = 0; dq_n = wave >= NW - 2 ? ND : 0;
+  } else if (key_base >= Npad) { dq_hh = 0; dq_dt0 = 0; dq_n = ND; }
   else if (8 * KT * 16 > Npad) { dq_hh = 1; dq_dt0 = wave - 4; dq_n = (wave >= 4 && wave < 4 + ND) ? 1 : 0; }
   else { dq_hh = (wave - 2) / ND; dq_dt0 = (wave - 2) - dq_hh * ND; dq_n = wave >= 2 ? 1 : 0; }
 
@@ -958,7 +959,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd4_kernel(const bf16* __restric
     const int ln = opaque(lane);
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
-      const int p = wave + 8 * i;
+      const int p = wave + NW * i;
       if (p < pieces) {  // wave-uniform; piece p = 64 consecutive 16-byte chunks of the image, lane -> (row, slot)
         const int ci = p * 64 + ln, row = ci / CH, slot = ci - row * CH;
         const uint32_t src = (uint32_t)((DH == 48 ? slot : (slot ^ ((row >> 1) & 7))) * 16);
@@ -971,7 +972,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd4_kernel(const bf16* __restric
   };
   // own V rows, O chunks (for delta) and lse values of an item, into registers
   RowFrag<DH> vfN[KT];
-  bf16x8 oN[4];
+  constexpr int NU = (Npad * 8 + NW * 64 - 1) / (NW * 64);  // 16-byte O chunks per thread
+  bf16x8 oN[NU];
   float lN = 0.f;
   auto prefetch_regs = [&](int item) {
     const int bh = item_bh(item), b = bh / H, h = bh - b * H;
@@ -981,18 +983,18 @@ __global__ void __launch_bounds__(512, 2) attn_bwd4_kernel(const bf16* __restric
     for (int t = 0; t < KT; ++t) vfN[t] = rows_global<DH>(vb, rs, key_base + t * 16, ln, N);
     const bf16* ob = o + (int64_t)b * N * os + h * DH;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + u * 512, r = idx >> 3, c = idx & 7;
+    for (int u = 0; u < NU; ++u) {
+      const int idx = tid + u * NW * 64, r = idx >> 3, c = idx & 7;
       oN[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
       if (r < N && c * 8 < DH) oN[u] = *reinterpret_cast<const bf16x8*>(ob + (int64_t)r * os + c * 8);
     }
     lN = tid < N ? lse[(int64_t)bh * N + tid] : 0.f;
   };
 
-  // (testing, dbg & 0x80) phase stamps of workgroup 0, waves 0 / 4 / 7, first four items: 10 per item, kept in the spare LDS
+  // (testing, dbg & 0x80) phase stamps of workgroup 0, waves 0 / NW/2 / NW-1, first four items: 10 per item, kept in the spare LDS
   // behind the dS^T buffers and dumped one per token row into the dQ slice of the workgroup's last item
   unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(dsT0 + 2 * dstsz);
-  const int swave = wave == 0 ? 0 : wave == 4 ? 1 : wave == 7 ? 2 : -1;
+  const int swave = wave == 0 ? 0 : wave == NW / 2 ? 1 : wave == NW - 1 ? 2 : -1;
 #define BWD4_STAMP(k_) do { if ((dbg & 0x80) && blockIdx.x == 0 && swave >= 0 && it < 4 && lane == 0) { __builtin_amdgcn_sched_barrier(0); stamps[(swave * 4 + it) * 10 + (k_)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
   int item = blockIdx.x;
   if (item >= nbh) return;
@@ -1019,9 +1021,10 @@ __global__ void __launch_bounds__(512, 2) attn_bwd4_kernel(const bf16* __restric
     for (int t = 0; t < KT; ++t) vf[t] = vfN[t];
     // delta[r] = sum_d dO[r,d] O[r,d] from the dO image and the prefetched O registers (8 lanes per row), stored times the
     // softmax scale: dS = P (dP scale - delta scale)
+    const int tid_top = wave * 64 + opaque(lane);  // (opaque: the offsets below are not worth registers across the query loop)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = threadIdx.x + u * 512, r = idx >> 3, c = idx & 7;
+    for (int u = 0; u < NU; ++u) {
+      const int idx = tid_top + u * NW * 64, r = idx >> 3, c = idx & 7;
       float part = 0.f;
       if (idx < Npad * 8 && c * 8 < DH) {
         const bf16x8 dv = *reinterpret_cast<const bf16x8*>(Dimg + HeadImg<DH>::off(r, c));
@@ -1033,7 +1036,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd4_kernel(const bf16* __restric
       part += __shfl_xor(part, 4, 64);
       if (idx < Npad * 8 && c == 0) sDel[r] = r < N ? part * scale : 0.f;
     }
-    if ((int)threadIdx.x < Npad) sLse[threadIdx.x] = (int)threadIdx.x < N ? lN * 1.44269504088896340736f : INFINITY;  // base 2; +inf: p = 0 on padded query rows
+    if (tid_top < Npad) sLse[tid_top] = tid_top < N ? lN * 1.44269504088896340736f : INFINITY;  // base 2; +inf: p = 0 on padded query rows
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     BWD4_STAMP(3);
@@ -1050,30 +1053,40 @@ __global__ void __launch_bounds__(512, 2) attn_bwd4_kernel(const bf16* __restric
     auto main_part = [&](int qbk) {
       const int q0 = qbk * 32;
       unsigned char* dsT = dsT0 + (qbk & 1) * dstsz;
+      // 128-register variant: per-lane LDS offsets recomputed per block (kept across the loop they were spilled, two scratch reloads per block)
+      const int ln = KT == 1 ? opaque(lane) : lane, g = ln >> 4;
       RowFrag<DH> qr[2], dr[2];
       f32x4 L4[2], D4[2];
+      if constexpr (KT > 1) {  // shared by the wave's key tiles: fetched once per block
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        qr[hh] = rows_lds<DH>(Qimg, q0 + 16 * hh, lane, true);
-        dr[hh] = rows_lds<DH>(Dimg, q0 + 16 * hh, lane, true);
-        L4[hh] = *reinterpret_cast<const f32x4*>(sLse + q0 + 16 * hh + 4 * g);
-        D4[hh] = *reinterpret_cast<const f32x4*>(sDel + q0 + 16 * hh + 4 * g);
+        for (int hh = 0; hh < 2; ++hh) {
+          qr[hh] = rows_lds<DH>(Qimg, q0 + 16 * hh, ln, true);
+          dr[hh] = rows_lds<DH>(Dimg, q0 + 16 * hh, ln, true);
+          L4[hh] = *reinterpret_cast<const f32x4*>(sLse + q0 + 16 * hh + 4 * g);
+          D4[hh] = *reinterpret_cast<const f32x4*>(sDel + q0 + 16 * hh + 4 * g);
+        }
       }
       bf16x8 qT[ND], dT[ND];
 #pragma unroll
       for (int dt = 0; dt < ND; ++dt) {
-        qT[dt] = cols_lds<DH>(Qimg, q0, q0 + 16, dt * 16, lane);
-        dT[dt] = cols_lds<DH>(Dimg, q0, q0 + 16, dt * 16, lane);
+        qT[dt] = cols_lds<DH>(Qimg, q0, q0 + 16, dt * 16, ln);
+        dT[dt] = cols_lds<DH>(Dimg, q0, q0 + 16, dt * 16, ln);
       }
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
         const int key0 = key_base + t * 16;  // < Npad: Npad is a multiple of 32
-        const RowFrag<DH> kf = rows_lds<DH>(Kimg, key0, lane, false);
-        const int key = key0 + (lane & 15);
+        const RowFrag<DH> kf = rows_lds<DH>(Kimg, key0, ln, false);
+        const int key = key0 + (ln & 15);
         const float keep = key < N ? 1.f : 0.f;
         f32x4 P[2], dS[2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
+          if constexpr (KT == 1) {  // one key tile per wave (128 registers): the two query halves one after the other
+            qr[hh] = rows_lds<DH>(Qimg, q0 + 16 * hh, ln, true);
+            dr[hh] = rows_lds<DH>(Dimg, q0 + 16 * hh, ln, true);
+            L4[hh] = *reinterpret_cast<const f32x4*>(sLse + q0 + 16 * hh + 4 * g);
+            D4[hh] = *reinterpret_cast<const f32x4*>(sDel + q0 + 16 * hh + 4 * g);
+          }
           const f32x4 sacc = mma_rows<DH>(qr[hh], kf, f32x4{0, 0, 0, 0});    // S[q = 4g+r][key = lane&15]
           const f32x4 dp = mma_rows<DH>(dr[hh], vf[t], f32x4{0, 0, 0, 0});   // dP[q][key]
 #pragma unroll
@@ -1110,22 +1123,30 @@ __global__ void __launch_bounds__(512, 2) attn_bwd4_kernel(const bf16* __restric
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
       };
-      // every fragment of the product is requested before the first MFMA (the registers of the main part are free here): the
-      // seven steps then run back to back instead of one LDS round trip each
+      // the fragments of the product are requested ahead of the MFMAs that use them (the registers of the main part are free
+      // here), in one go where they fit and in halves of the key range otherwise: the steps then run back to back instead of
+      // one LDS round trip each
       f32x4 dq[NT];
-      bf16x8 kT[nqb][NT], bq[nqb];
-#pragma unroll
-      for (int kb = 0; kb < nqb; ++kb) {
-        bq[kb] = ds_frag(kb * 32);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) kT[kb][j] = cols_lds<DH>(Kimg, kb * 32, kb * 32 + 16, (dt0 + j) * 16, ln);
-      }
 #pragma unroll
       for (int j = 0; j < NT; ++j) dq[j] = f32x4{0, 0, 0, 0};
+      constexpr int kHalf = (KT == 1 && NT > 1) ? (nqb + 1) / 2 : nqb;
 #pragma unroll
-      for (int kb = 0; kb < nqb; ++kb)
+      for (int k0 = 0; k0 < nqb; k0 += kHalf) {
+        bf16x8 kT[kHalf][NT], bq[kHalf];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) dq[j] = MFMA(kT[kb][j], bq[kb], dq[j]);
+        for (int kb = 0; kb < kHalf; ++kb)
+          if (k0 + kb < nqb) {
+            bq[kb] = ds_frag((k0 + kb) * 32);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) kT[kb][j] = cols_lds<DH>(Kimg, (k0 + kb) * 32, (k0 + kb) * 32 + 16, (dt0 + j) * 16, ln);
+          }
+#pragma unroll
+        for (int kb = 0; kb < kHalf; ++kb)
+          if (k0 + kb < nqb) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) dq[j] = MFMA(kT[kb][j], bq[kb], dq[j]);
+          }
+      }
       const int q = qbk * 32 + 16 * hh + (ln & 15);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
@@ -1137,11 +1158,11 @@ __global__ void __launch_bounds__(512, 2) attn_bwd4_kernel(const bf16* __restric
     };
     const bool owns_keys = key_base < Npad;
     for (int qbk = 0; qbk < nqb; ++qbk) {
-      if (wave < 4) {
+      if (wave < NW / 2) {
         if (owns_keys && !(dbg & 0x100)) main_part(qbk);
-        if (qbk > 0 && !(dbg & 0x200)) dq_part(qbk - 1, lane);
+        if (qbk > 0 && !(dbg & 0x200)) dq_part(qbk - 1, KT == 1 ? opaque(lane) : lane);  // (128-register variant: nothing hoisted out of the item loop)
       } else {
-        if (qbk > 0 && !(dbg & 0x200)) dq_part(qbk - 1, lane);
+        if (qbk > 0 && !(dbg & 0x200)) dq_part(qbk - 1, KT == 1 ? opaque(lane) : lane);
         if (owns_keys && !(dbg & 0x100)) main_part(qbk);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1388,6 +1409,11 @@ int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const fl
     constexpr size_t l4 = bwd4_lds<48>(224);
     static_assert(l4 <= (size_t)kMaxLds, "bwd4 LDS");
     const int nbh = B * H, grid = nbh < ncu ? nbh : ncu;
+    if (g_attn_bwd3 & 16) {  // 16 waves x one key tile, four waves per SIMD (default)
+      if (int rc = set_lds(attn_bwd4_kernel<48, 224, 1>, l4)) return rc;
+      hipLaunchKernelGGL((attn_bwd4_kernel<48, 224, 1>), dim3(grid), dim3(1024), l4, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, N, H, (bf16*)dqkv, nbh, g_attn_dbg & 0xF80);
+      return check_hip(hipGetLastError(), "attention_bwd4");
+    }
     if (int rc = set_lds(attn_bwd4_kernel<48, 224>, l4)) return rc;
     hipLaunchKernelGGL((attn_bwd4_kernel<48, 224>), dim3(grid), dim3(512), l4, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, N, H, (bf16*)dqkv, nbh, g_attn_dbg & 0xF80);
     return check_hip(hipGetLastError(), "attention_bwd4");

@@ -7,7 +7,7 @@ lib = _lib.load(); dev = torch.device("cuda"); st = torch.cuda.current_stream().
 B, N, H, dh = 256, 217, 16, 48
 qkv = torch.randn(B, N, 3 * H * dh, device=dev).bfloat16(); d_o = torch.randn(B, N, H * dh, device=dev).bfloat16()
 o = torch.randn(B, N, H * dh, device=dev).bfloat16(); lse = torch.randn(B, H, N, device=dev) + 5; dq = torch.empty_like(qkv)
-lib.hct_debug_force_simple_attention(100004)
+lib.hct_debug_force_simple_attention(100000 + int(sys.argv[1]) if len(sys.argv) > 1 else 100004)
 names = ["top", "own loads landed", "barrier 1", "delta + barrier 2", "DMA issued", "q-block 0", "q-block 1", "q loop done", "reg prefetch + dQ tail", "stores issued"]
 for extra, nm in ((0, "full"), (0x100, "no main"), (0x200, "no dQ")):
     lib.hct_debug_force_simple_attention(10 + 0x80 + extra)
@@ -23,4 +23,4 @@ for extra, nm in ((0, "full"), (0x100, "no main"), (0x200, "no dQ")):
             v = [(rows[(w * 4 + it) * 10 + k] - t0) / 100.0 for k in range(10)]
             print(f"wave {wn} item {it}: " + " ".join(f"{x:7.2f}" for x in v))
 print("columns: " + " | ".join(names))
-lib.hct_debug_force_simple_attention(10); lib.hct_debug_force_simple_attention(100006)
+lib.hct_debug_force_simple_attention(10); lib.hct_debug_force_simple_attention(100022)
