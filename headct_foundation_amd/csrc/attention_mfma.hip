@@ -18,7 +18,7 @@
 
 namespace hct {
 
-int g_attn_bwd3 = 22;  // bit4: bwd4 as 16 waves x one key tile (128 registers, four waves per SIMD: 287 vs 305 us, -0.09 ms per step) instead of 8 x two.  bit3 (opt-in: measured equal to the kernel it would replace, 116 vs 117 us): persistent forward (fwd4) for head dim 48 with 193 .. 224 tokens.  Which shapes use the key-owner five-product backward: bit0 head dim 48 (<= 256 tokens, bwd3), bit1 head dim 64 (<= 192 tokens, bwd3), bit2 head dim 48 with 193 .. 224 tokens (persistent bwd4)
+int g_attn_bwd3 = 54;  // bit5: the encoder's bwd3 instance is four waves x one key tile (44.7 us) instead of two x two (53.5 us).  bit4: bwd4 as 16 waves x one key tile (128 registers, four waves per SIMD: 287 vs 305 us, -0.09 ms per step) instead of 8 x two.  bit3 (opt-in: measured equal to the kernel it would replace, 116 vs 117 us): persistent forward (fwd4) for head dim 48 with 193 .. 224 tokens.  Which shapes use the key-owner five-product backward: bit0 head dim 48 (<= 256 tokens, bwd3), bit1 head dim 64 (<= 192 tokens, bwd3), bit2 head dim 48 with 193 .. 224 tokens (persistent bwd4)
 int g_attn_dbg = 0;  // timing experiments on the backward kernel: bit0 skip key-owner pass, bit1 skip query-owner pass
 
 namespace {
@@ -1429,6 +1429,7 @@ int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const fl
     return check_hip(hipGetLastError(), "attention_bwd3");                                                             \
   } while (0)
     if (dh == 48 && Npad <= 256 && (g_attn_bwd3 & 1)) { if (g_attn_dbg & 64) HCT_BWD3(48, 4, 4, 1); else HCT_BWD3(48, 4, 4, 2); }  // 64: one wave per SIMD (testing)
+    if (dh == 64 && Npad <= 64 && (g_attn_bwd3 & 2) && (g_attn_bwd3 & 32)) HCT_BWD3(64, 4, 1, 4);  // four waves x one key tile per head, 128 registers (default)
     if (dh == 64 && Npad <= 64 && (g_attn_bwd3 & 2)) HCT_BWD3(64, 2, 2, 2);
     if (dh == 64 && Npad <= 192 && (g_attn_bwd3 & 2)) HCT_BWD3(64, 4, 3, 2);
 #undef HCT_BWD3

@@ -144,7 +144,7 @@ def test_attention_fwd_bwd(lib, cuda, B, N, H, dh, dtype):
     # 0 default (five-product key-owner backward where it applies), 1 fp32-math kernels, 2 online-softmax forward,
     # 14 single-phase backward, 42 two-phase seven-product backward
     # 100003: bwd3 key-owner backward on every shape it covers (the default uses it for head dim 64 only); 100000: two-phase
-    # everywhere; 100014: the opt-in persistent forward (fwd4) and the 8-wave form of bwd4; the default (100022) takes the 16-wave
+    # everywhere; 100014: the opt-in persistent forward (fwd4) and the 8-wave form of bwd4; the default (100054) takes the 16-wave
     # persistent bwd4 for head dim 48
     # with 193 .. 224 tokens -- the last two cases
     # have more (batch, head) items than CUs, so its workgroups walk several items through both LDS buffers
@@ -161,7 +161,7 @@ def test_attention_fwd_bwd(lib, cuda, B, N, H, dh, dtype):
         finally:
             lib.hct_debug_force_simple_attention(0)
             lib.hct_debug_force_simple_attention(10)
-            lib.hct_debug_force_simple_attention(100022)
+            lib.hct_debug_force_simple_attention(100054)
         assert rel_err(o, o_ref) < tol, force_simple
         assert (lse - lse_ref).abs().max() < (2e-2 if dtype == torch.bfloat16 else 1e-4)
         assert torch.isfinite(dqkv.float()).all()
