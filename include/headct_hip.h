@@ -373,7 +373,13 @@ void hct_prof_enable(int mask); /* bit i enables kernel class i; 0 = off */
 void hct_prof_reset(void);
 int hct_prof_read(int id, double* total_ms, int64_t* launches, double* work);
 int hct_prof_read_bytes(int id, double* bytes); /* algorithmic bytes (operands read once + outputs written once) of those launches */
-/* testing hook: route bf16 attention through the fp32-math kernels */
+/* testing hook, attention kernel choice (tests and scripts/ab_step.py only):
+ *   0 / 1        default / every call through the fp32-math kernels;   2 / 3  online-softmax / full-row MFMA forward
+ *   10 + bits    backward experiment bits (4 single-phase, 8 four-wave two-phase, 32 two-phase everywhere, 64 one wave per
+ *                SIMD, 0x80 phase stamps, 0x100 .. 0x800 timing ablations -- outputs are then garbage)
+ *   100000 + m   which shapes take the key-owner backward kernels: bit0 bwd3 for head dim 48, bit1 bwd3 for head dim 64,
+ *                bit2 persistent bwd4 (head dim 48, 193 .. 224 tokens), bit3 persistent forward fwd4 (same shapes),
+ *                bit4 bwd4 as 16 waves x one key tile, bit5 encoder bwd3 as four waves x one key tile; default 54 */
 void hct_debug_force_simple_attention(int on);
 /* testing hook: force the NT GEMM tile variant (0 auto, 128, 256) */
 void hct_debug_set_gemm_variant(int v);
