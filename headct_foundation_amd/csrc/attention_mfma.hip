@@ -260,22 +260,27 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_row_kernel(const bf16* __res
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) st[t] = MFMA(frag_row(Kimg, t * 16, ks, lane), qf[ks], st[t]);
     }
-    float mx = -INFINITY;
+    // row maximum of the raw scores (scale > 0), keys >= N masked; only the tiles that can hold such keys carry the mask: the
+    // dispatch (attention_fwd_mfma: instances NT = 4, 10, 14, 18, the smallest that fits) uses this instance only for sequences
+    // longer than the previous instance's 16 * kPrevNT keys
+    constexpr int kPrevNT = NT <= 4 ? 0 : NT <= 10 ? 4 : NT <= 14 ? 10 : 14;
+    float mraw = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        st[t][r] = (t * 16 + 4 * g + r < N) ? st[t][r] * scale : -INFINITY;
-        mx = fmaxf(mx, st[t][r]);
+        if (t >= kPrevNT && t * 16 + 4 * g + r >= N) st[t][r] = -INFINITY;
+        mraw = fmaxf(mraw, st[t][r]);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mraw = fmaxf(mraw, __shfl_xor(mraw, 16, 64));
+    mraw = fmaxf(mraw, __shfl_xor(mraw, 32, 64));
+    const float mx = mraw * scale;
     float ps = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        st[t][r] = __builtin_amdgcn_exp2f(st[t][r] - mx);
+        st[t][r] = __builtin_amdgcn_exp2f(fmaf(st[t][r], scale, -mx));  // one fma + exp per score
         ps += st[t][r];
       }
     ps += __shfl_xor(ps, 16, 64);
@@ -1386,7 +1391,7 @@ int attention_fwd_mfma(const void* qkv, int B, int N, int H, int dh, void* o, fl
   }
   if (g_attn_row) {  // full-row kernels for the MAE token counts (<= 64, <= 160, <= 224, <= 288 keys)
     const int nt = Npad / 16;
-#define HCT_ROW(DH_, NT_) if (dh == DH_ && nt <= NT_) return launch_fwd_row<DH_, NT_>(qkv, B, N, H, o, lse, s)
+#define HCT_ROW(DH_, NT_) if (dh == DH_ && nt <= NT_) return launch_fwd_row<DH_, NT_>(qkv, B, N, H, o, lse, s)  /* ascending NT: the kernel's kPrevNT relies on it */
     HCT_ROW(64, 4); HCT_ROW(48, 4); HCT_ROW(64, 10); HCT_ROW(48, 10); HCT_ROW(64, 14); HCT_ROW(48, 14); HCT_ROW(64, 18); HCT_ROW(48, 18);
 #undef HCT_ROW
   }
