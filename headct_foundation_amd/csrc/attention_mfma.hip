@@ -52,6 +52,22 @@ __device__ __forceinline__ void load_image(unsigned char* img, const bf16* __res
   }
 }
 
+// LDS-DMA fill of a 128-byte-row image (img_off: 8 chunks per row, XOR swizzle) whatever the head dim, 1 KiB pieces dealt to the waves:
+// for head dim 48 the two chunks behind the head's 96 bytes are the next head's (or the next token's) data -- finite bf16 that
+// only ever meets the zero-padded Q fragment -- or zero where they fall outside the tensor (the range check uses the true width).
+__device__ __forceinline__ void dma_image128(unsigned char* img, const bf16* __restrict__ g, int64_t rs, int N, int Npad, int valid_cols,
+                                             int wave, int nwaves, int lane) {
+  const int64_t bytes = ((int64_t)(N - 1) * rs + valid_cols) * 2;
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)bytes, 0x00020000);
+  const int pieces = Npad * 8 / 64;
+  for (int p = wave; p < pieces; p += nwaves) {
+    const int ci = p * 64 + lane;
+    const int row = ci >> 3, slot = ci & 7;
+    const uint32_t voff = (uint32_t)(row * (int)rs * 2 + ((slot ^ ((row >> 1) & 7)) << 4));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(img + p * 1024), 16, voff, 0, 0, 0);
+  }
+}
+
 // delta[r] = sum_d dO[r,d] * O[r,d] and lse[r] into LDS.  8 lanes per row (one 16-B chunk each, coalesced 96/128-B row
 // reads, 3 shuffle steps) with all loads of a thread issued before their use; the old one-thread-per-row form touched 64
 // different cache lines per wave instruction and serialised 12 of them per thread.
@@ -144,7 +160,6 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma_kernel(const bf16* __restri
   load_image<DH>(Vimg, qb + 2 * H * DH, rs, N, Npad, 256);
   __syncthreads();
   const float scale = rsqrtf((float)DH);
-  const float scale2 = scale * 1.44269504088896340736f;  // softmax probabilities are rebuilt in base 2 (lse is stored * log2 e)
   const int g = lane >> 4;
   constexpr int ND = DH / 16;
   const int nqt = (N + 15) >> 4;
@@ -243,9 +258,9 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_row_kernel(const bf16* __res
       qall[it][ks] = v;
     }
   }
-  load_image<DH>(Kimg, qb + H * DH, rs, N, Npad, NW * 64);
-  load_image<DH>(Vimg, qb + 2 * H * DH, rs, N, Npad, NW * 64);
-  __syncthreads();
+  dma_image128(Kimg, qb + H * DH, rs, N, Npad, DH, wave, NW, lane);  // (no registers, no VALU, no LDS stores on the way)
+  dma_image128(Vimg, qb + 2 * H * DH, rs, N, Npad, DH, wave, NW, lane);
+  __syncthreads();  // (with a DMA in flight hipcc's barrier waits vmcnt(0) first)
   const float scale = rsqrtf((float)DH) * 1.44269504088896340736f;  // fold log2(e): softmax in base 2
 #pragma unroll
   for (int it = 0; it < MAXT; ++it) {
@@ -255,10 +270,9 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_row_kernel(const bf16* __res
     bf16x8 qf[2] = {qall[it][0], qall[it][1]};
     f32x4 st[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      st[t] = f32x4{0, 0, 0, 0};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) st[t] = MFMA(frag_row(Kimg, t * 16, ks, lane), qf[ks], st[t]);
+    for (int t = 0; t < NT; ++t) {  // (a literal zero accumulator input: no register zeroing)
+      st[t] = MFMA(frag_row(Kimg, t * 16, 0, lane), qf[0], (f32x4{0, 0, 0, 0}));
+      st[t] = MFMA(frag_row(Kimg, t * 16, 1, lane), qf[1], st[t]);
     }
     // row maximum of the raw scores (scale > 0), keys >= N masked; only the tiles that can hold such keys carry the mask: the
     // dispatch (attention_fwd_mfma: instances NT = 4, 10, 14, 18, the smallest that fits) uses this instance only for sequences
