@@ -289,17 +289,15 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_row_kernel(const bf16* __res
     mraw = fmaxf(mraw, __shfl_xor(mraw, 16, 64));
     mraw = fmaxf(mraw, __shfl_xor(mraw, 32, 64));
     const float mx = mraw * scale;
-    float ps = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        st[t][r] = __builtin_amdgcn_exp2f(fmaf(st[t][r], scale, -mx));  // one fma + exp per score
-        ps += st[t][r];
-      }
-    ps += __shfl_xor(ps, 16, 64);
-    ps += __shfl_xor(ps, 32, 64);
-    f32x4 oacc[ND];
+      for (int r = 0; r < 4; ++r) st[t][r] = __builtin_amdgcn_exp2f(fmaf(st[t][r], scale, -mx));  // one fma + exp per score
+    // The row sum rides on the matrix pipe (the kernel is VALU-issue bound, the MFMAs are 13 % busy): one more "d-tile" whose V^T
+    // rows 4g are all ones gives sum_key P[key][q] in element 0 of every lane -- of the bf16-rounded P, as the numerator uses.
+    const bf16 one = (bf16)1.0f, zero = (bf16)0.0f, ov = (lane & 3) == 0 ? one : zero;
+    const bf16x8 ones_rows = {ov, ov, ov, ov, ov, ov, ov, ov};
+    f32x4 oacc[ND], psum = {0, 0, 0, 0};
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt) oacc[dt] = f32x4{0, 0, 0, 0};
 #pragma unroll
@@ -307,7 +305,9 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_row_kernel(const bf16* __res
       const bf16x8 pb = pack8(st[2 * s2], st[2 * s2 + 1]);
 #pragma unroll
       for (int dt = 0; dt < ND; ++dt) oacc[dt] = MFMA(frag_tr(Vimg, s2 * 32, s2 * 32 + 16, dt * 16, lane), pb, oacc[dt]);
+      psum = MFMA(ones_rows, pb, psum);
     }
+    const float ps = psum[0];
     if (q < N) {
       const float inv = 1.0f / ps;
       bf16* orow = o + ((int64_t)b * N + q) * (H * DH) + h * DH + 4 * g;
