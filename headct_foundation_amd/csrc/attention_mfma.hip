@@ -1038,6 +1038,8 @@ __global__ void __launch_bounds__(1024 / KT, 2 * 2 / KT) attn_bwd4_kernel(const 
     RowFrag<DH> vf[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) vf[t] = vfN[t];
+    RowFrag<DH> kfh = vf[0];  // (KT == 1 only) this wave's K rows, zero-padded: read once per item
+    if constexpr (KT == 1) kfh = rows_lds<DH>(Kimg, key_base < Npad ? key_base : 0, opaque(lane), true);
     // delta[r] = sum_d dO[r,d] O[r,d] from the dO image and the prefetched O registers (8 lanes per row), stored times the
     // softmax scale: dS = P (dP scale - delta scale)
     const int tid_top = wave * 64 + opaque(lane);  // (opaque: the offsets below are not worth registers across the query loop)
@@ -1080,7 +1082,7 @@ __global__ void __launch_bounds__(1024 / KT, 2 * 2 / KT) attn_bwd4_kernel(const 
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           qr[hh] = rows_lds<DH>(Qimg, q0 + 16 * hh, ln, true);
-          dr[hh] = rows_lds<DH>(Dimg, q0 + 16 * hh, ln, true);
+          dr[hh] = rows_lds<DH>(Dimg, q0 + 16 * hh, ln, false);  // (its partner, the V fragment, is the zero-padded side)
           L4[hh] = *reinterpret_cast<const f32x4*>(sLse + q0 + 16 * hh + 4 * g);
           D4[hh] = *reinterpret_cast<const f32x4*>(sDel + q0 + 16 * hh + 4 * g);
         }
@@ -1094,15 +1096,17 @@ __global__ void __launch_bounds__(1024 / KT, 2 * 2 / KT) attn_bwd4_kernel(const 
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
         const int key0 = key_base + t * 16;  // < Npad: Npad is a multiple of 32
-        const RowFrag<DH> kf = rows_lds<DH>(Kimg, key0, ln, false);
+        // KT == 1: the wave's K fragment is fetched (and zero-padded) once per item, so the Q / dO fragments stream unpadded
+        const RowFrag<DH> kf = KT == 1 ? kfh : rows_lds<DH>(Kimg, key0, ln, false);
         const int key = key0 + (ln & 15);
         const float keep = key < N ? 1.f : 0.f;
+        const bool tail_tile = key0 + 16 > N;  // wave-uniform: only the tile that straddles N masks its probabilities
         f32x4 P[2], dS[2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           if constexpr (KT == 1) {  // one key tile per wave (128 registers): the two query halves one after the other
-            qr[hh] = rows_lds<DH>(Qimg, q0 + 16 * hh, ln, true);
-            dr[hh] = rows_lds<DH>(Dimg, q0 + 16 * hh, ln, true);
+            qr[hh] = rows_lds<DH>(Qimg, q0 + 16 * hh, ln, false);
+            dr[hh] = rows_lds<DH>(Dimg, q0 + 16 * hh, ln, false);
             L4[hh] = *reinterpret_cast<const f32x4*>(sLse + q0 + 16 * hh + 4 * g);
             D4[hh] = *reinterpret_cast<const f32x4*>(sDel + q0 + 16 * hh + 4 * g);
           }
@@ -1110,7 +1114,8 @@ __global__ void __launch_bounds__(1024 / KT, 2 * 2 / KT) attn_bwd4_kernel(const 
           const f32x4 dp = mma_rows<DH>(dr[hh], vf[t], f32x4{0, 0, 0, 0});   // dP[q][key]
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            P[hh][r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale2, -L4[hh][r])) * keep;
+            P[hh][r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale2, -L4[hh][r]));
+            if (tail_tile) P[hh][r] *= keep;
             dS[hh][r] = P[hh][r] * fmaf(dp[r], scale, -D4[hh][r]);
           }
         }
