@@ -246,18 +246,21 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_row_kernel(const bf16* __res
   const int nqt = (N + 15) >> 4;
   // Q fragments of all of this wave's query tiles are fetched up front, together with the K/V images, so their HBM
   // latency is paid once per workgroup instead of once per query tile
-  bf16x8 qall[MAXT][2];
-#pragma unroll
-  for (int it = 0; it < MAXT; ++it) {
+  // (kept to two tiles ahead: with the long score rows of the 34-tile instances more of them cost an accumulator its registers)
+  constexpr int QA = MAXT <= 2 ? MAXT : 1;
+  bf16x8 qall[QA][2];
+  auto load_q = [&](int it, bf16x8* dst) {
     const int q = (wave + it * NW) * 16 + (lane & 15);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int d = ks * 32 + 8 * g;
       bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
       if (q < N && d < DH) v = *reinterpret_cast<const bf16x8*>(qb + (int64_t)q * rs + d);
-      qall[it][ks] = v;
+      dst[ks] = v;
     }
-  }
+  };
+#pragma unroll
+  for (int it = 0; it < QA; ++it) load_q(it, qall[it]);
   dma_image128(Kimg, qb + H * DH, rs, N, Npad, DH, wave, NW, lane);  // (no registers, no VALU, no LDS stores on the way)
   dma_image128(Vimg, qb + 2 * H * DH, rs, N, Npad, DH, wave, NW, lane);
   __syncthreads();  // (with a DMA in flight hipcc's barrier waits vmcnt(0) first)
@@ -267,7 +270,10 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_row_kernel(const bf16* __res
     const int qt = wave + it * NW;
     if (qt >= nqt) break;
     const int q = qt * 16 + (lane & 15);
-    bf16x8 qf[2] = {qall[it][0], qall[it][1]};
+    bf16x8 qf[2];
+    if constexpr (MAXT <= 2) { qf[0] = qall[it][0]; qf[1] = qall[it][1]; }
+    else if (it == 0) { qf[0] = qall[0][0]; qf[1] = qall[0][1]; }
+    else load_q(it, qf);
     f32x4 st[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {  // (a literal zero accumulator input: no register zeroing)
@@ -275,9 +281,9 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_row_kernel(const bf16* __res
       st[t] = MFMA(frag_row(Kimg, t * 16, 1, lane), qf[1], st[t]);
     }
     // row maximum of the raw scores (scale > 0), keys >= N masked; only the tiles that can hold such keys carry the mask: the
-    // dispatch (attention_fwd_mfma: instances NT = 4, 10, 14, 18, the smallest that fits) uses this instance only for sequences
+    // dispatch (attention_fwd_mfma: instances NT = 4, 10, 14, 18, 34, the smallest that fits) uses this instance only for sequences
     // longer than the previous instance's 16 * kPrevNT keys
-    constexpr int kPrevNT = NT <= 4 ? 0 : NT <= 10 ? 4 : NT <= 14 ? 10 : 14;
+    constexpr int kPrevNT = NT <= 4 ? 0 : NT <= 10 ? 4 : NT <= 14 ? 10 : NT <= 18 ? 14 : 18;
     float mraw = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -1408,10 +1414,11 @@ int attention_fwd_mfma(const void* qkv, int B, int N, int H, int dh, void* o, fl
     hipLaunchKernelGGL((attn_fwd4_kernel<48, 224>), dim3(grid), dim3(1024), l4, s, (const bf16*)qkv, N, H, (bf16*)o, lse, nbh, g_attn_dbg & 0xF00);
     return check_hip(hipGetLastError(), "attention_fwd4");
   }
-  if (g_attn_row) {  // full-row kernels for the MAE token counts (<= 64, <= 160, <= 224, <= 288 keys)
+  if (g_attn_row) {  // full-row kernels (<= 64, <= 160, <= 224, <= 288, <= 544 keys)
     const int nt = Npad / 16;
 #define HCT_ROW(DH_, NT_) if (dh == DH_ && nt <= NT_) return launch_fwd_row<DH_, NT_>(qkv, B, N, H, o, lse, s)  /* ascending NT: the kernel's kPrevNT relies on it */
     HCT_ROW(64, 4); HCT_ROW(48, 4); HCT_ROW(64, 10); HCT_ROW(48, 10); HCT_ROW(64, 14); HCT_ROW(48, 14); HCT_ROW(64, 18); HCT_ROW(48, 18);
+    HCT_ROW(64, 34); HCT_ROW(48, 34);  // 289 .. 544 keys (DINO: 517 tokens, ViT-L decoder: 513): 139 KB of K / V images, one workgroup per CU, 256-register waves
 #undef HCT_ROW
   }
   if (dh == 48) {
