@@ -470,7 +470,7 @@ __device__ __forceinline__ bf16x8 gfrag(const bf16* __restrict__ base, int64_t r
 #define HCT_BWD2_WPE 4
 #endif
 template <int DH, int NW>
-__global__ void __launch_bounds__(NW * 64, (NW == 8 ? HCT_BWD2_WPE : 2)) attn_bwd2_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+__global__ void __launch_bounds__(NW * 64, (NW >= 8 ? HCT_BWD2_WPE : 2)) attn_bwd2_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                                 const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                                 int N, int H, int Npad, bf16* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -493,6 +493,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? HCT_BWD2_WPE : 2)) attn_bw
   constexpr int ND = DH / 16;
   const int npair = Npad >> 5;
 
+  // The next owned tile's fragments are prefetched one tile ahead -- except for head dim 64, where those 16 registers are
+  // what the 128-register budget lacks (14 spilled registers, reloaded in the inner loop); there the tile's fragments are
+  // fetched at its start, once per 17+ query pairs of work.
+  constexpr bool kAhead = DH != 64;
   // ---- pass 1: Q, dO streamed from LDS; the wave owns 16-key tiles (dK, dV) --------------------------------
   bf16x8 kf[2], vf[2], kn[2], vn[2];
 #pragma unroll
@@ -508,8 +512,13 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? HCT_BWD2_WPE : 2)) attn_bw
     const int key0 = kt * 16;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {  // prefetch the next owned tile (zero beyond N)
-      kn[ks] = gfrag<DH>(kb, rs, key0 + NW * 16, ks, lane, N);
-      vn[ks] = gfrag<DH>(vb, rs, key0 + NW * 16, ks, lane, N);
+      if (kAhead) {
+        kn[ks] = gfrag<DH>(kb, rs, key0 + NW * 16, ks, lane, N);
+        vn[ks] = gfrag<DH>(vb, rs, key0 + NW * 16, ks, lane, N);
+      } else if (kt != wave) {
+        kf[ks] = gfrag<DH>(kb, rs, key0, ks, lane, N);
+        vf[ks] = gfrag<DH>(vb, rs, key0, ks, lane, N);
+      }
     }
     const bool key_ok = key0 + (lane & 15) < N;
     f32x4 dKt[ND], dVt[ND];
@@ -552,8 +561,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? HCT_BWD2_WPE : 2)) attn_bw
         Vec4<bf16>::store(outv + dt * 16, dVt[dt]);
       }
     }
+    if (kAhead) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
+      for (int ks = 0; ks < 2; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
+    }
   }
 
   // ---- pass 2: K, V streamed from LDS; the wave owns 16-query tiles (dQ) -----------------------------------
@@ -571,8 +582,13 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? HCT_BWD2_WPE : 2)) attn_bw
     const int q0 = qt * 16;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      qn[ks] = gfrag<DH>(qb, rs, q0 + NW * 16, ks, lane, N);
-      dn[ks] = gfrag<DH>(dob, os, q0 + NW * 16, ks, lane, N);
+      if (kAhead) {
+        qn[ks] = gfrag<DH>(qb, rs, q0 + NW * 16, ks, lane, N);
+        dn[ks] = gfrag<DH>(dob, os, q0 + NW * 16, ks, lane, N);
+      } else if (qt != wave) {
+        qf[ks] = gfrag<DH>(qb, rs, q0, ks, lane, N);
+        dof[ks] = gfrag<DH>(dob, os, q0, ks, lane, N);
+      }
     }
     const float Lq = sLse[q0 + (lane & 15)], Dq = sDel[q0 + (lane & 15)];
     f32x4 dQt[ND];
@@ -606,8 +622,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? HCT_BWD2_WPE : 2)) attn_bw
 #pragma unroll
       for (int dt = 0; dt < ND; ++dt) Vec4<bf16>::store(outq + dt * 16, dQt[dt]);
     }
+    if (kAhead) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) { qf[ks] = qn[ks]; dof[ks] = dn[ks]; }
+      for (int ks = 0; ks < 2; ++ks) { qf[ks] = qn[ks]; dof[ks] = dn[ks]; }
+    }
   }
 }
 
@@ -1474,8 +1492,10 @@ int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const fl
                        (const bf16*)o, (const bf16*)d_o, lse, N, H, Npad, (bf16*)dqkv);                              \
   } while (0)
     const bool w8 = (g_attn_dbg & 8) ? false : N > 64;  // 8 waves (16 per CU) once there are enough tiles to share
-    if (dh == 48) { if (w8) HCT_BWD2(48, 8); else HCT_BWD2(48, 4); }
-    else { if (w8) HCT_BWD2(64, 8); else HCT_BWD2(64, 4); }
+    // beyond ~80 KB of images only one workgroup fits a CU: 16 waves (four per SIMD at the same 128 registers) instead of 8
+    const bool w16 = w8 && l2 > (size_t)81408 && !(g_attn_bwd3 & 64);
+    if (dh == 48) { if (w16) HCT_BWD2(48, 16); else if (w8) HCT_BWD2(48, 8); else HCT_BWD2(48, 4); }
+    else { if (w16) HCT_BWD2(64, 16); else if (w8) HCT_BWD2(64, 8); else HCT_BWD2(64, 4); }
 #undef HCT_BWD2
     return check_hip(hipGetLastError(), "attention_bwd2_mfma");
   }
