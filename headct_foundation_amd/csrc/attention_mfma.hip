@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(NW * 64, (NW >= 8 ? HCT_BWD2_WPE : 2)) attn_bw
   }
   load_image<DH>(img0, qb, rs, N, Npad, NW * 64);
   load_image<DH>(img1, dob, os, N, Npad, NW * 64);
-  compute_delta<DH>(ob, dob, os, lse + (int64_t)bh * N, N, Npad, sLse, sDel, NW * 64);
+  compute_delta<DH>(ob, dob, os, lse + (int64_t)bh * N, N, Npad, sLse, sDel, NW * 64, 1.44269504088896340736f, scale);  // delta stored times the softmax scale
   __syncthreads();
   for (int kt = wave; kt * 16 < N; kt += NW) {
     const int key0 = kt * 16;
@@ -521,6 +521,7 @@ __global__ void __launch_bounds__(NW * 64, (NW >= 8 ? HCT_BWD2_WPE : 2)) attn_bw
       }
     }
     const bool key_ok = key0 + (lane & 15) < N;
+    const bool tail_tile = key0 + 16 > N;  // wave-uniform: only the tile that straddles N masks its probabilities
     f32x4 dKt[ND], dVt[ND];
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt) dKt[dt] = dVt[dt] = f32x4{0, 0, 0, 0};
@@ -539,9 +540,10 @@ __global__ void __launch_bounds__(NW * 64, (NW >= 8 ? HCT_BWD2_WPE : 2)) attn_bw
         const f32x4 D4 = *reinterpret_cast<const f32x4*>(sDel + q0 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = key_ok ? __builtin_amdgcn_exp2f(sacc[r] * scale2 - L4[r]) : 0.f;
+          float pv = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale2, -L4[r]));  // (padded query rows: L = +inf -> 0)
+          if (tail_tile && !key_ok) pv = 0.f;
           P[hh][r] = pv;
-          dS[hh][r] = pv * (dp[r] - D4[r]) * scale;
+          dS[hh][r] = pv * fmaf(dp[r], scale, -D4[r]);
         }
       }
       const bf16x8 pa = pack8(P[0], P[1]);
@@ -590,7 +592,7 @@ __global__ void __launch_bounds__(NW * 64, (NW >= 8 ? HCT_BWD2_WPE : 2)) attn_bw
         dof[ks] = gfrag<DH>(dob, os, q0, ks, lane, N);
       }
     }
-    const float Lq = sLse[q0 + (lane & 15)], Dq = sDel[q0 + (lane & 15)];
+    const float Lq = sLse[q0 + (lane & 15)], Dq = sDel[q0 + (lane & 15)];  // (Dq = delta * scale)
     f32x4 dQt[ND];
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt) dQt[dt] = f32x4{0, 0, 0, 0};
@@ -607,8 +609,9 @@ __global__ void __launch_bounds__(NW * 64, (NW >= 8 ? HCT_BWD2_WPE : 2)) attn_bw
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = (k0 + 4 * g + r < N) ? __builtin_amdgcn_exp2f(sacc[r] * scale2 - Lq) : 0.f;
-          dS[hh][r] = pv * (dp[r] - Dq) * scale;
+          float pv = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale2, -Lq));
+          if (k0 + 16 > N && k0 + 4 * g + r >= N) pv = 0.f;  // (the first test is wave-uniform: only the last key tile pays for the mask)
+          dS[hh][r] = pv * fmaf(dp[r], scale, -Dq);
         }
       }
       const bf16x8 dsb = pack8(dS[0], dS[1]);
