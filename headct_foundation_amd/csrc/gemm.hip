@@ -1766,7 +1766,9 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
         HCT_CHECK_LAUNCH("hct_gemm(nt_w4)");
         return finish_colsum(false);
       }
-      const bool fuse_cs = a->colsum_out && mode == EPI_DGELU_BF16 && a->M % 256 == 0 && !w4;
+      // (any M: rows past M are masked out of the sums, and every (row tile, wave) partial row is written -- zeros where a
+      //  wave's 64 rows lie wholly past M -- so the fixed-order fold over ceil(M / 256) * 4 rows sees no stale data)
+      const bool fuse_cs = a->colsum_out && mode == EPI_DGELU_BF16 && !w4;
       if (fuse_cs) e.colsum_partial = (float*)workspace;
       const dim3 grid(std::min(tiles256, num_cus()));
       // one start phase = 1/8 of a tile's main loop (nk stages x ~1000 cycles; s_sleep(32) = 2048 cycles); only when each

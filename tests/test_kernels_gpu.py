@@ -277,8 +277,8 @@ def test_clip_and_adamw_vs_torch(lib, cuda):
 
 
 def test_gemm_dgelu_fused_colsum(lib, cuda):
-    """dgrad through GELU with the fused bias-gradient column sum (persistent NT kernel) and the separate-pass fallback."""
-    for M, N, K in ((512, 768, 256), (217 * 2, 3072, 768), (256, 256, 128)):
+    """dgrad through GELU with the fused bias-gradient column sum (persistent NT kernel), whole and partial row tiles."""
+    for M, N, K in ((512, 768, 256), (217 * 2, 3072, 768), (256, 256, 128), (1000, 3072, 256), (70000, 512, 128)):  # partial last row tiles; more tiles than CUs
         A = _rand((M, K), cuda, torch.bfloat16, 51)
         B = _rand((N, K), cuda, torch.bfloat16, 52, 0.05)
         aux = _rand((M, N), cuda, torch.bfloat16, 53)
