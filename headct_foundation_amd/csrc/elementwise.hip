@@ -549,7 +549,14 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const T* __restrict
   const int r1 = min(rows, r0 + rows_per_chunk);
   f32x4 acc = {0, 0, 0, 0};
   if (c0 < cols)
-    for (int r = r0 + wave; r < r1; r += 4) acc += Vec4<T>::load(x + (size_t)r * ld + c0);
+    for (int r = r0 + wave; r < r1; r += 4 * 8) {  // 8 row loads in flight per lane; added in row order (same sums as one by one)
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = r + 4 * u < r1 ? Vec4<T>::load(x + (size_t)(r + 4 * u) * ld + c0) : f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r + 4 * u < r1) acc += v[u];
+    }
 #pragma unroll
   for (int e = 0; e < 4; ++e) s_red[wave][lane * 4 + e] = acc[e];
   __syncthreads();
