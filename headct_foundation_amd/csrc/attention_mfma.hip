@@ -1483,7 +1483,9 @@ int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const fl
     if (dh == 48 && Npad <= 256 && (g_attn_bwd3 & 1)) { if (g_attn_dbg & 64) HCT_BWD3(48, 4, 4, 1); else HCT_BWD3(48, 4, 4, 2); }  // 64: one wave per SIMD (testing)
     if (dh == 64 && Npad <= 64 && (g_attn_bwd3 & 2) && (g_attn_bwd3 & 32)) HCT_BWD3(64, 4, 1, 4);  // four waves x one key tile per head, 128 registers (default)
     if (dh == 64 && Npad <= 64 && (g_attn_bwd3 & 2)) HCT_BWD3(64, 2, 2, 2);
-    if (dh == 64 && Npad <= 192 && (g_attn_bwd3 & 2)) HCT_BWD3(64, 4, 3, 2);
+    // 65 .. 192 tokens at head dim 64 (ViT-L encoder: 129): the two-phase kernel is faster (58.9 us against 84.8 for this instance
+    // and 83.6 for twelve waves x one key tile), so bwd3 takes them only when forced onto every shape it covers (bits 0 and 1)
+    if (dh == 64 && Npad <= 192 && (g_attn_bwd3 & 3) == 3) HCT_BWD3(64, 4, 3, 2);
 #undef HCT_BWD3
   }
   if (!(g_attn_dbg & 4) || bwd_lds(N) > (size_t)kMaxLds) {  // single-phase variant (testing hook) only where its 4 images fit

@@ -39,3 +39,13 @@ for B, N, H in ((3, 55, 12), (40, 55, 12), (7, 33, 5), (5, 64, 3)):
 for mask, nm in ((0, "two-phase"), (2, "bwd3, 2 waves x 2 key tiles"), (34, "bwd3, 4 waves x 1 key tile")):
     _, us = bwd(256, 55, 12, 64, mask, reps=30)
     print(f"encoder B=256 N=55 H=12 dh=64 [{nm}]: {us:6.1f} us", flush=True)
+for B, N, H in ((3, 129, 16), (5, 160, 3), (4, 100, 2)):
+    a, _ = bwd(B, N, H, 64, 0)
+    for mask in (3,):
+        b, _ = bwd(B, N, H, 64, mask)
+        err = ((a.float() - b.float()).norm() / a.float().norm()).item()
+        assert bool(torch.isfinite(b.float()).all()) and err < 1e-2, (B, N, H, mask, err)
+    print(f"B={B} N={N} H={H}: bwd3 instances agree with the two-phase kernel", flush=True)
+for mask, nm in ((0, "two-phase"), (3, "bwd3, 4 waves x 3 key tiles"), (54, "default")):
+    _, us = bwd(64, 129, 16, 64, mask, reps=30)
+    print(f"ViT-L encoder B=64 N=129 H=16 dh=64 [{nm}]: {us:6.1f} us", flush=True)
