@@ -134,7 +134,8 @@ def _attn_ref(qkv, B, N, H, dh):
                                             (3, 256, 2, 48, torch.bfloat16), (2, 192, 2, 64, torch.bfloat16),
                                             (20, 217, 16, 48, torch.bfloat16), (37, 193, 8, 48, torch.bfloat16),
                                             (2, 70, 3, 64, torch.bfloat16), (2, 165, 2, 48, torch.bfloat16), (2, 226, 2, 48, torch.bfloat16),
-                                            (2, 517, 3, 64, torch.bfloat16), (1, 300, 2, 48, torch.bfloat16)])  # lowest lengths of the forward's 10 / 14 / 18-tile instances
+                                            (2, 517, 3, 64, torch.bfloat16), (1, 300, 2, 48, torch.bfloat16),
+                                            (3, 224, 2, 48, torch.bfloat16), (3, 208, 2, 48, torch.bfloat16)])  # bwd4: no padded key at all / a key tile wholly past N  # lowest lengths of the forward's 10 / 14 / 18-tile instances
 def test_attention_fwd_bwd(lib, cuda, B, N, H, dh, dtype):
     qkv = _rand((B, N, 3 * H * dh), cuda, dtype, 11)
     d_o = _rand((B, N, H * dh), cuda, dtype, 12)
