@@ -40,8 +40,21 @@ for sub, name, mul in (("fetch", "FETCH_SIZE", 2.0), ("write", "WRITE_SIZE", 1.0
     for k, c in a.items():
         if k in res["kernels"] and name in c:
             res["kernels"][k][name.lower() + "_bytes_per_launch" + ("_x2_corrected" if mul == 2.0 else "")] = round(c[name] / m[k][name] * 1024 * mul)
+# VALU / MFMA / LDS instruction counters of the third pass (wave-instructions per launch; VALU counts include the MFMAs)
+a, m = counters("valu")
+for k, c in a.items():
+    if k not in res["kernels"]:
+        continue
+    e = res["kernels"][k]
+    for name, key in (("SQ_INSTS_VALU", "valu_wave_insts_per_launch"), ("SQ_INSTS_MFMA", "mfma_wave_insts_per_launch"),
+                      ("SQ_ACTIVE_INST_VALU", "valu_active_cycles_per_launch"), ("SQ_ACTIVE_INST_LDS", "lds_active_cycles_per_launch")):
+        if name in c and m[k][name]:
+            e[key] = round(c[name] / m[k][name])
+    if "valu_wave_insts_per_launch" in e and e.get("clock_GHz"):
+        # share of the launch the SIMDs would spend issuing those instructions at 4 clocks each (an issue-bound estimate, 1024 SIMDs)
+        e["valu_issue_frac_at_4clk"] = round(e["valu_wave_insts_per_launch"] * 4 / 1024 / (e["avg_us"] * 1e3 * e["clock_GHz"]), 3)
 res["note"] = ("mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs); FETCH_SIZE doubled per the gfx950 correction "
-               "(MI355X_MICROARCH.md, HBM); separate rocprofv3 passes of `bench.py --steps 5 --warmup 2`")
+               "(MI355X_MICROARCH.md, HBM); valu_issue_frac_at_4clk = SQ_INSTS_VALU * 4 clk / 1024 SIMDs / launch cycles; separate rocprofv3 passes of `bench.py --steps 5 --warmup 2`")
 json.dump(res, open(out_json, "w"), indent=1)
 tot = sum(v["ms_per_step"] for v in res["kernels"].values())
 print(f"sum of kernel time: {tot:.2f} ms/step")
