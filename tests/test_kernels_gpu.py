@@ -277,6 +277,32 @@ def test_clip_and_adamw_vs_torch(lib, cuda):
     assert torch.equal(shadow[:seg[3]], p[:seg[3]].to(torch.bfloat16))
 
 
+def test_epilogue_gelu_accuracy_on_a_grid(lib, cuda):
+    """The GELU / GELU' of the MFMA GEMM epilogues (clamped polynomial normal CDF, csrc/common.h) on a grid of pre-activations
+    in [-10, 10]: against the exact-erf functions of the reference (nn.GELU(), MONAI MLPBlock) the error stays within the bf16
+    rounding of the stored value plus 2e-4 (the polynomial's own bound is 1.4e-4 for gelu, 3.5e-5 for gelu')."""
+    M, N, K = 256, 4096, 128
+    x = torch.linspace(-10.0, 10.0, N, device=cuda)
+    A = torch.zeros(M, K, dtype=torch.bfloat16, device=cuda)
+    B = _rand((N, K), cuda, torch.bfloat16, 3)
+    # forward: out = gelu(0 + bias), aux = the pre-activation as stored
+    aux = torch.empty(M, N, dtype=torch.bfloat16, device=cuda)
+    out = gemm(lib, A, B, 0, 1, M, N, K, out_dtype=torch.bfloat16, bias=x, act=1, aux=aux)
+    want = F.gelu(x)
+    ulp = want.abs() * 2.0 ** -8 + 1e-30
+    assert torch.equal(aux[0].float(), x.bfloat16().float())
+    assert float(((out[0].float() - want).abs() - ulp).max()) < 2e-4 and torch.equal(out[0], out[-1])
+    # backward factor: out = (ones . ones^T) * gelu'(aux)   (K ones: 128, exact in bf16)
+    A1 = torch.ones(M, K, dtype=torch.bfloat16, device=cuda)
+    B1 = torch.ones(N, K, dtype=torch.bfloat16, device=cuda)
+    u = aux.float().requires_grad_(True)
+    F.gelu(u).sum().backward()
+    out2 = gemm(lib, A1, B1, 0, 1, M, N, K, out_dtype=torch.bfloat16, act=2, aux=aux)
+    want2 = K * u.grad
+    ulp2 = want2.abs() * 2.0 ** -8
+    assert float(((out2.float() - want2).abs() - ulp2).max()) < K * 2e-4
+
+
 def test_gemm_dgelu_fused_colsum(lib, cuda):
     """dgrad through GELU with the fused bias-gradient column sum (persistent NT kernel), whole and partial row tiles."""
     for M, N, K in ((512, 768, 256), (217 * 2, 3072, 768), (256, 256, 128), (1000, 3072, 256), (70000, 512, 128)):  # partial last row tiles; more tiles than CUs
