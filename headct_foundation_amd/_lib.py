@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libheadct_hip.so")
 
 HCT_F32, HCT_BF16, HCT_F16 = 0, 1, 2
-HCT_ACT_NONE, HCT_ACT_GELU, HCT_ACT_DGELU, HCT_ACT_TANH = 0, 1, 2, 3
+HCT_ACT_NONE, HCT_ACT_GELU, HCT_ACT_DGELU, HCT_ACT_TANH, HCT_ACT_GELU_D, HCT_ACT_MULAUX = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
 
 c_void_p, c_int, c_float, c_size_t, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64

@@ -130,6 +130,13 @@ __device__ __forceinline__ float dgelu_fast(float x) {
   const float E = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));
   return fmaf(x * 0.39894228040143267794f, E, gelu_cdf_poly(x));
 }
+// both at once (the forward epilogue that saves gelu' instead of the pre-activation): one CDF polynomial, one exponential
+__device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
+  const float cdf = gelu_cdf_poly(x);
+  const float E = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));
+  g = x * cdf;
+  dg = fmaf(x * 0.39894228040143267794f, E, cdf);
+}
 #else  // diagnostic build (A/B of the two forms): erf by Abramowitz-Stegun 7.1.26, gelu and gelu' sharing the exponential
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
   const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752440f, 1.0f));
@@ -144,6 +151,7 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
 }
 __device__ __forceinline__ float gelu_fast(float x) { float c, p; gelu_parts(x, c, p); return x * c; }
 __device__ __forceinline__ float dgelu_fast(float x) { float c, p; gelu_parts(x, c, p); return fmaf(x, p, c); }
+__device__ __forceinline__ void gelu_both(float x, float& g, float& dg) { float c, p; gelu_parts(x, c, p); g = x * c; dg = fmaf(x, p, c); }
 #endif
 
 // dispatch a storage dtype code to a template parameter

@@ -33,6 +33,7 @@ struct Epilogue {
   void* C2; int c2_dtype; int64_t ldc2;
   float alpha;
   float* colsum_partial;  // [ceil(M/256)*4][N] per-(tile-row, wave-row) column sums of the output (DGELU mode), or null
+  int aux_deriv;          // HCT_ACT_GELU_D / HCT_ACT_MULAUX: aux holds gelu'(pre-activation) instead of the pre-activation
 };
 
 __device__ __forceinline__ void store4(void* base, int dtype, int64_t off, f32x4 v) {
@@ -54,13 +55,20 @@ __device__ __forceinline__ void epilogue4(const Epilogue& e, int m, int n, f32x4
   f32x4 v = acc * e.alpha;
   if (e.bias) v += Vec4<float>::load(e.bias + n);
   if (e.act == HCT_ACT_GELU) {
-    if (e.aux) store4(e.aux, e.aux_dtype, (int64_t)m * e.ldaux + n, v);
+    if (e.aux) {
+      f32x4 sv = v;
+      if (e.aux_deriv) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sv[i] = dgelu_erf(v[i]);
+      }
+      store4(e.aux, e.aux_dtype, (int64_t)m * e.ldaux + n, sv);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
   } else if (e.act == HCT_ACT_DGELU) {
     const f32x4 u = load4(e.aux, e.aux_dtype, (int64_t)m * e.ldaux + n);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] *= dgelu_erf(u[i]);
+    for (int i = 0; i < 4; ++i) v[i] *= e.aux_deriv ? u[i] : dgelu_erf(u[i]);
   }
   if (e.residual) v += Vec4<float>::load(e.residual + (int64_t)m * e.ldr + n);
   store4(e.C, e.c_dtype, (int64_t)m * e.ldc + n, v);
@@ -85,12 +93,19 @@ __device__ __forceinline__ void epilogue_row(const Epilogue& e, int m, int n0, i
     if (n >= N) continue;
     f32x4 v = acc[j] * e.alpha + bv[j];
     if (e.act == HCT_ACT_GELU) {
-      if (e.aux) store4(e.aux, e.aux_dtype, (int64_t)m * e.ldaux + n, v);
+      if (e.aux) {
+      f32x4 sv = v;
+      if (e.aux_deriv) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sv[i] = dgelu_erf(v[i]);
+      }
+      store4(e.aux, e.aux_dtype, (int64_t)m * e.ldaux + n, sv);
+    }
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
     } else if (e.act == HCT_ACT_DGELU) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] *= dgelu_erf(u[j][i]);
+      for (int i = 0; i < 4; ++i) v[i] *= e.aux_deriv ? u[j][i] : dgelu_erf(u[j][i]);
     }
     v += r[j];
     store4(e.C, e.c_dtype, (int64_t)m * e.ldc + n, v);
@@ -131,12 +146,19 @@ __device__ __forceinline__ void epilogue_tile16x64(const Epilogue& e, unsigned c
     if (!(nok && m < M)) continue;
     f32x4 x = v[it] * e.alpha + bv;
     if (e.act == HCT_ACT_GELU) {
-      if (e.aux) store4(e.aux, e.aux_dtype, (int64_t)m * e.ldaux + n, x);
+      if (e.aux) {
+        f32x4 sv = x;
+        if (e.aux_deriv) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sv[i] = dgelu_erf(x[i]);
+        }
+        store4(e.aux, e.aux_dtype, (int64_t)m * e.ldaux + n, sv);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) x[i] = gelu_erf(x[i]);
     } else if (e.act == HCT_ACT_DGELU) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) x[i] *= dgelu_erf(u[it][i]);
+      for (int i = 0; i < 4; ++i) x[i] *= e.aux_deriv ? u[it][i] : dgelu_erf(u[it][i]);
     }
     x += r[it];
     store4(e.C, e.c_dtype, (int64_t)m * e.ldc + n, x);
@@ -148,10 +170,13 @@ __device__ __forceinline__ void epilogue1(const Epilogue& e, int m, int n, float
   float v = acc * e.alpha;
   if (e.bias) v += e.bias[n];
   if (e.act == HCT_ACT_GELU) {
-    if (e.aux) store1(e.aux, e.aux_dtype, (int64_t)m * e.ldaux + n, v);
+    if (e.aux) store1(e.aux, e.aux_dtype, (int64_t)m * e.ldaux + n, e.aux_deriv ? dgelu_erf(v) : v);
     v = gelu_erf(v);
   } else if (e.act == HCT_ACT_DGELU) {
-    v *= dgelu_erf(load1(e.aux, e.aux_dtype, (int64_t)m * e.ldaux + n));
+    {
+      const float u = load1(e.aux, e.aux_dtype, (int64_t)m * e.ldaux + n);
+      v *= e.aux_deriv ? u : dgelu_erf(u);
+    }
   }
   if (e.residual) v += e.residual[(int64_t)m * e.ldr + n];
   store1(e.C, e.c_dtype, (int64_t)m * e.ldc + n, v);
@@ -340,12 +365,19 @@ __device__ __forceinline__ void epilogue_tile16x64_swz(const Epilogue& e, unsign
     if (!(nok && m < M)) continue;
     f32x4 x = v[it] * e.alpha + bv;
     if (e.act == HCT_ACT_GELU) {
-      if (e.aux) store4(e.aux, e.aux_dtype, (int64_t)m * e.ldaux + n, x);
+      if (e.aux) {
+        f32x4 sv = x;
+        if (e.aux_deriv) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sv[i] = dgelu_erf(x[i]);
+        }
+        store4(e.aux, e.aux_dtype, (int64_t)m * e.ldaux + n, sv);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) x[i] = gelu_erf(x[i]);
     } else if (e.act == HCT_ACT_DGELU) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) x[i] *= dgelu_erf(u[it][i]);
+      for (int i = 0; i < 4; ++i) x[i] *= e.aux_deriv ? u[it][i] : dgelu_erf(u[it][i]);
     }
     x += r[it];
     store4(e.C, e.c_dtype, (int64_t)m * e.ldc + n, x);
@@ -383,12 +415,19 @@ __device__ __forceinline__ void epilogue_tile16x128(const Epilogue& e, unsigned 
       if (!(nok && m < M)) continue;
       f32x4 x = v[it] * e.alpha + bv;
       if (e.act == HCT_ACT_GELU) {
-        if (e.aux) store4(e.aux, e.aux_dtype, (int64_t)m * e.ldaux + n, x);
+        if (e.aux) {
+        f32x4 sv = x;
+        if (e.aux_deriv) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sv[i] = dgelu_erf(x[i]);
+        }
+        store4(e.aux, e.aux_dtype, (int64_t)m * e.ldaux + n, sv);
+      }
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i] = gelu_erf(x[i]);
       } else if (e.act == HCT_ACT_DGELU) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] *= dgelu_erf(u[it][i]);
+        for (int i = 0; i < 4; ++i) x[i] *= e.aux_deriv ? u[it][i] : dgelu_erf(u[it][i]);
       }
       x += r[it];
       store4(e.C, e.c_dtype, (int64_t)m * e.ldc + n, x);
@@ -559,19 +598,40 @@ __device__ __forceinline__ void epilogue_wave64x128_m(const Epilogue& e, const T
           return __builtin_bit_cast(u32x4, o);
         };
         if (MODE == EPI_GELU_BF16) {
-          __builtin_amdgcn_raw_buffer_store_b128(pack(x0, x1), tb.aux, vx, sx, kNT);
-          HCT_STORE_GUARD();
+          if (e.aux_deriv) {  // aux receives gelu'(pre-activation): the backward then multiplies by it (no second evaluation)
+            f32x4 d0, d1;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            x0[q] = gelu_fast(x0[q]);
-            x1[q] = gelu_fast(x1[q]);
+            for (int q = 0; q < 4; ++q) {
+              float ga, da, gb, db;
+              gelu_both(x0[q], ga, da);
+              gelu_both(x1[q], gb, db);
+              x0[q] = ga; d0[q] = da; x1[q] = gb; d1[q] = db;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(pack(d0, d1), tb.aux, vx, sx, kNT);
+            HCT_STORE_GUARD();
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(pack(x0, x1), tb.aux, vx, sx, kNT);
+            HCT_STORE_GUARD();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              x0[q] = gelu_fast(x0[q]);
+              x1[q] = gelu_fast(x1[q]);
+            }
           }
         } else if (MODE == EPI_DGELU_BF16 || MODE == EPI_DGELU_CS) {
           const bf16x8 t = __builtin_bit_cast(bf16x8, ld[i & 1][it]);
+          if (e.aux_deriv) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            x0[q] *= dgelu_fast((float)t[q]);
-            x1[q] *= dgelu_fast((float)t[4 + q]);
+            for (int q = 0; q < 4; ++q) {
+              x0[q] *= (float)t[q];
+              x1[q] *= (float)t[4 + q];
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              x0[q] *= dgelu_fast((float)t[q]);
+              x1[q] *= dgelu_fast((float)t[4 + q]);
+            }
           }
           if (MODE == EPI_DGELU_CS) {  // fused bias gradient of the Linear feeding the GELU (column sums of this output)
             cs0 += ok ? x0 : f32x4{0, 0, 0, 0};
@@ -672,19 +732,40 @@ __device__ __forceinline__ void epilogue_wave64x128_h(const Epilogue& e, const T
           return __builtin_bit_cast(u32x4, o);
         };
         if (MODE == EPI_GELU_BF16) {
-          __builtin_amdgcn_raw_buffer_store_b128(pack(x0, x1), tb.aux, vx, sx, kNT);
-          HCT_STORE_GUARD();
+          if (e.aux_deriv) {  // aux receives gelu'(pre-activation): the backward then multiplies by it (no second evaluation)
+            f32x4 d0, d1;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            x0[q] = gelu_fast(x0[q]);
-            x1[q] = gelu_fast(x1[q]);
+            for (int q = 0; q < 4; ++q) {
+              float ga, da, gb, db;
+              gelu_both(x0[q], ga, da);
+              gelu_both(x1[q], gb, db);
+              x0[q] = ga; d0[q] = da; x1[q] = gb; d1[q] = db;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(pack(d0, d1), tb.aux, vx, sx, kNT);
+            HCT_STORE_GUARD();
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(pack(x0, x1), tb.aux, vx, sx, kNT);
+            HCT_STORE_GUARD();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              x0[q] = gelu_fast(x0[q]);
+              x1[q] = gelu_fast(x1[q]);
+            }
           }
         } else if (MODE == EPI_DGELU_BF16 || MODE == EPI_DGELU_CS) {
           const bf16x8 t = __builtin_bit_cast(bf16x8, ld[s & 1][it]);
+          if (e.aux_deriv) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            x0[q] *= dgelu_fast((float)t[q]);
-            x1[q] *= dgelu_fast((float)t[4 + q]);
+            for (int q = 0; q < 4; ++q) {
+              x0[q] *= (float)t[q];
+              x1[q] *= (float)t[4 + q];
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              x0[q] *= dgelu_fast((float)t[q]);
+              x1[q] *= dgelu_fast((float)t[4 + q]);
+            }
           }
           if (MODE == EPI_DGELU_CS) {  // fused bias gradient of the Linear feeding the GELU (column sums of this output)
             cs[h][0] += ok ? x0 : f32x4{0, 0, 0, 0};
@@ -1596,7 +1677,9 @@ static bool aligned_to(const void* p, size_t a) { return p == nullptr || ((uintp
 
 static Epilogue make_epilogue(const hct_gemm_args* a) {
   Epilogue e;
-  e.bias = a->bias; e.residual = a->residual; e.ldr = a->ldr; e.act = a->act;
+  e.bias = a->bias; e.residual = a->residual; e.ldr = a->ldr;
+  e.aux_deriv = a->act == HCT_ACT_GELU_D || a->act == HCT_ACT_MULAUX;
+  e.act = a->act == HCT_ACT_GELU_D ? HCT_ACT_GELU : a->act == HCT_ACT_MULAUX ? HCT_ACT_DGELU : a->act;
   e.aux = a->aux; e.aux_dtype = a->aux_dtype; e.ldaux = a->ldaux;
   e.C = a->C; e.c_dtype = a->c_dtype; e.ldc = a->ldc;
   e.C2 = a->C2; e.c2_dtype = a->c2_dtype; e.ldc2 = a->ldc2;
@@ -1654,8 +1737,9 @@ static int epilogue_mode(const hct_gemm_args* a) {
   if (a->c_dtype == HCT_BF16 && !(a->N % 8 == 0 && wide_ok(a->C, a->ldc) && wide_ok(a->aux, a->ldaux))) return EPI_GENERIC;
   if (a->act == HCT_ACT_NONE && !a->residual && a->c_dtype == HCT_BF16) return EPI_PLAIN_BF16;
   if (a->act == HCT_ACT_NONE && a->residual && a->c_dtype == HCT_F32) return EPI_RES_F32;
-  if (a->act == HCT_ACT_GELU && !a->residual && a->c_dtype == HCT_BF16 && a->aux && a->aux_dtype == HCT_BF16) return EPI_GELU_BF16;
-  if (a->act == HCT_ACT_DGELU && !a->residual && a->c_dtype == HCT_BF16 && a->aux_dtype == HCT_BF16) return EPI_DGELU_BF16;
+  const bool is_gelu = a->act == HCT_ACT_GELU || a->act == HCT_ACT_GELU_D, is_dgelu = a->act == HCT_ACT_DGELU || a->act == HCT_ACT_MULAUX;
+  if (is_gelu && !a->residual && a->c_dtype == HCT_BF16 && a->aux && a->aux_dtype == HCT_BF16) return EPI_GELU_BF16;
+  if (is_dgelu && !a->residual && a->c_dtype == HCT_BF16 && a->aux_dtype == HCT_BF16) return EPI_DGELU_BF16;
   return EPI_GENERIC;
 }
 
@@ -1710,7 +1794,8 @@ size_t hct_gemm_workspace_bytes(const hct_gemm_args* a) {
 
 int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, void* stream) {
   HCT_REQUIRE(a && a->M >= 0 && a->N >= 0 && a->K >= 0, "hct_gemm: bad shape");
-  HCT_REQUIRE(a->act != HCT_ACT_DGELU || a->aux, "hct_gemm: DGELU needs aux");
+  HCT_REQUIRE((a->act != HCT_ACT_DGELU && a->act != HCT_ACT_MULAUX && a->act != HCT_ACT_GELU_D) || a->aux, "hct_gemm: DGELU / MULAUX / GELU_D need aux");
+  HCT_REQUIRE(a->act >= HCT_ACT_NONE && a->act <= HCT_ACT_MULAUX && a->act != HCT_ACT_TANH, "hct_gemm: unknown activation code %d", a->act);
   if (a->M == 0 || a->N == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   Epilogue e = make_epilogue(a);

@@ -268,6 +268,14 @@ size_t wgrad_ws(int dt, int M, int N, int K) {
     if (_rc) return _rc; \
   } while (0)
 
+// The MLP's saved activation is gelu'(pre-activation), written by the fc1 epilogue from the unrounded value; the fc2 dgrad then
+// multiplies by it (HCT_ACT_GELU_D / HCT_ACT_MULAUX) instead of evaluating gelu' a second time from a bf16-rounded input.
+#ifdef HCT_PLAN_RECOMPUTE_DGELU  // diagnostic build (A/B): the pre-activation is saved and gelu' recomputed in the backward
+constexpr int kActFc1 = HCT_ACT_GELU, kActFc2Dgrad = HCT_ACT_DGELU;
+#else
+constexpr int kActFc1 = HCT_ACT_GELU_D, kActFc2Dgrad = HCT_ACT_MULAUX;
+#endif
+
 int block_forward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const float* h_in, float* h_out, int B, int N, int d,
                   int m, int heads, hipStream_t s) {
   const int M = B * N;
@@ -277,7 +285,7 @@ int block_forward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const flo
   RC(hct_attention_fwd(ws + ba.qkv, B, N, heads, d / heads, p->dt, ws + ba.o, (float*)(ws + ba.lse), s));
   RC(linear_fwd(p, ws + ba.o, M, d, bp.proj_w, bp.proj_b, d, ws + ba.h_mid, HCT_F32, HCT_ACT_NONE, nullptr, h_in, s));
   RC(hct_layernorm_fwd((const float*)(ws + ba.h_mid), p->pf(bp.ln2_w), p->pf(bp.ln2_b), M, d, 1e-5f, ws + ba.x2, p->dt, (float*)(ws + ba.mean2), (float*)(ws + ba.rstd2), s));
-  RC(linear_fwd(p, ws + ba.x2, M, d, bp.fc1_w, bp.fc1_b, m, ws + ba.g, p->dt, HCT_ACT_GELU, ws + ba.u, nullptr, s));
+  RC(linear_fwd(p, ws + ba.x2, M, d, bp.fc1_w, bp.fc1_b, m, ws + ba.g, p->dt, kActFc1, ws + ba.u, nullptr, s));  // ba.u holds gelu'(pre-activation)
   RC(linear_fwd(p, ws + ba.g, M, m, bp.fc2_w, bp.fc2_b, d, h_out, HCT_F32, HCT_ACT_NONE, nullptr, (const float*)(ws + ba.h_mid), s));
   return 0;
 }
@@ -300,7 +308,7 @@ int block_backward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const fl
   // d(pre-GELU) = (dh . W2) * gelu'(u); the linear1 bias gradient = column sums of this output rides in the same
   // epilogue (colsum_out: per-row-tile partials + a fixed-order fold; hct_gemm falls back to a separate pass over the
   // output where the fused instance does not apply)
-  RC(linear_dgrad(p, dhs, M, d, bp.fc2_w, m, dbig, HCT_ACT_DGELU, ws + ba.u, s, p->gf(bp.fc1_b)));
+  RC(linear_dgrad(p, dhs, M, d, bp.fc2_w, m, dbig, kActFc2Dgrad, ws + ba.u, s, p->gf(bp.fc1_b)));
   RC(linear_wgrad(p, dbig, ws + ba.x2, M, m, d, bp.fc1_w, -1, s));
   RC(linear_dgrad(p, dbig, M, m, bp.fc1_w, d, dx, HCT_ACT_NONE, nullptr, s));
   RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + ba.h_mid), (const float*)(ws + ba.mean2), (const float*)(ws + ba.rstd2),

@@ -39,6 +39,8 @@ extern "C" {
 #define HCT_ACT_GELU 1  /* out = gelu_erf(acc + bias); aux (if given) receives the pre-activation */
 #define HCT_ACT_DGELU 2 /* out = acc * gelu_erf'(aux)   (aux = saved pre-activation)             */
 #define HCT_ACT_TANH 3  /* hct_head_linear only: out = tanh(acc + bias)                           */
+#define HCT_ACT_GELU_D 4 /* hct_gemm: out = gelu_erf(acc + bias); aux receives gelu_erf'(acc + bias) -- what the backward     */
+#define HCT_ACT_MULAUX 5 /* hct_gemm: out = acc * aux -- needs (the derivative is evaluated once, on the unrounded value)   */
 
 const char* hct_last_error_string(void);
 int hct_version(void);

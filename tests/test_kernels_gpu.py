@@ -303,6 +303,25 @@ def test_epilogue_gelu_accuracy_on_a_grid(lib, cuda):
     assert float(((out2.float() - want2).abs() - ulp2).max()) < K * 2e-4
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_saved_gelu_derivative(lib, cuda, dtype):
+    """HCT_ACT_GELU_D (out = gelu(acc + bias), aux <- gelu'(acc + bias)) and HCT_ACT_MULAUX (out = acc * aux): the pair the plan
+    uses for the MLP (attentionblock.py:91 / MONAI MLPBlock), on the MFMA path (bf16) and the generic path (fp32)."""
+    M, N, K = 300, 768, 256
+    A = _rand((M, K), cuda, dtype, 61)
+    B = _rand((N, K), cuda, dtype, 62, 0.05)
+    bias = _rand((N,), cuda, torch.float32, 63)
+    pre = (A.float() @ B.float().t() + bias).requires_grad_(True)
+    F.gelu(pre).sum().backward()
+    aux = torch.empty(M, N, dtype=dtype, device=cuda)
+    out = gemm(lib, A, B, 0, 1, M, N, K, out_dtype=dtype, bias=bias, act=4, aux=aux)
+    tol = 6e-3 if dtype == torch.bfloat16 else 1e-5
+    assert rel_err(out, F.gelu(pre.detach())) < tol and rel_err(aux, pre.grad) < tol
+    G = _rand((M, K), cuda, dtype, 64)
+    out2 = gemm(lib, G, B, 0, 1, M, N, K, out_dtype=dtype, act=5, aux=aux)
+    assert rel_err(out2, (G.float() @ B.float().t()) * aux.float()) < tol
+
+
 def test_gemm_dgelu_fused_colsum(lib, cuda):
     """dgrad through GELU with the fused bias-gradient column sum (persistent NT kernel), whole and partial row tiles."""
     for M, N, K in ((512, 768, 256), (217 * 2, 3072, 768), (256, 256, 128), (1000, 3072, 256), (70000, 512, 128)):  # partial last row tiles; more tiles than CUs
