@@ -482,6 +482,9 @@ __device__ __forceinline__ f32x4 bload_bf16x4(__amdgpu_buffer_rsrc_t r, uint32_t
 #define HCT_EPI_CACHE_POLICY 2  /* nt */
 #endif
 constexpr int kNT = HCT_EPI_CACHE_POLICY;
+#ifndef HCT_SLAB_POLICY
+#define HCT_SLAB_POLICY 16  /* cache policy of the wgrad's split-K slab stores: 16 = sc1 write-through (39.83 ms per step), 0 = write-back (39.90), 2 = nt (40.17) */
+#endif
 
 // Lane -> output mapping of the specialised epilogue:
 //   bf16 outputs ("wide" modes): lane = 4 rows x 16 lanes, 8 consecutive columns (16 B) per lane -> dwordx4 stores / loads.
@@ -1451,7 +1454,9 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
       f32x4 cs0 = {0, 0, 0, 0}, cs1 = {0, 0, 0, 0};
       // partial slabs leave write-through (sc1): they are handed to other workgroups below, and a write-through store needs
       // no release fence (publishing 256 KB of plain stores with buffer_wbl2 costs several us per workgroup)
-      if (slab) epilogue_wave64x128_m<EPI_PLAIN_F32, 16>(eo, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv, cs0, cs1);
+      // (with the separate fold kernel -- the default -- the kernel boundary publishes them: policy HCT_SLAB_POLICY)
+      if (slab && counters) epilogue_wave64x128_m<EPI_PLAIN_F32, 16>(eo, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv, cs0, cs1);
+      else if (slab) epilogue_wave64x128_m<EPI_PLAIN_F32, HCT_SLAB_POLICY>(eo, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv, cs0, cs1);
       else epilogue_wave64x128_m<EPI_PLAIN_F32>(eo, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv, cs0, cs1);
     }
     if (slab && counters) {  // publish this split's partial: every wave's stores have left, then ONE arrival on the tile's counter
