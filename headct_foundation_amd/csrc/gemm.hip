@@ -482,6 +482,9 @@ __device__ __forceinline__ f32x4 bload_bf16x4(__amdgpu_buffer_rsrc_t r, uint32_t
 #define HCT_EPI_CACHE_POLICY 2  /* nt */
 #endif
 constexpr int kNT = HCT_EPI_CACHE_POLICY;
+#ifndef HCT_RES_POLICY
+#define HCT_RES_POLICY 16  /* the fp32 residual-stream output, read back by the next LayerNorm: sc1 39.76 / write-back 39.77 / nt 39.84 ms per step */
+#endif
 #ifndef HCT_SLAB_POLICY
 #define HCT_SLAB_POLICY 16  /* cache policy of the wgrad's split-K slab stores: 16 = sc1 write-through (39.83 ms per step), 0 = write-back (39.90), 2 = nt (40.17) */
 #endif
@@ -1058,7 +1061,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
         tb.res = tile_rsrc(MODE == EPI_RES_F32 ? (const void*)e.residual : nullptr, e.ldr, 4, cm0, cn0, M, N);
         tb.aux = tile_rsrc((MODE == EPI_GELU_BF16 || MODE == EPI_DGELU_BF16 || MODE == EPI_DGELU_CS) ? e.aux : nullptr, e.ldaux, 2, cm0, cn0, M, N);
         f32x4 cs[2][2] = {{f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}};
-        epilogue_wave64x128_h<MODE>(e, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bh, cs);
+        epilogue_wave64x128_h<MODE, (MODE == EPI_RES_F32 ? HCT_RES_POLICY : kNT)>(e, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bh, cs);
         if (MODE == EPI_DGELU_CS) {  // lanes l, l+8, ..., l+56 hold 8 different rows of the same 8 columns
 #pragma unroll
           for (int h = 0; h < 2; ++h)
