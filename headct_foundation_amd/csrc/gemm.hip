@@ -482,6 +482,9 @@ __device__ __forceinline__ f32x4 bload_bf16x4(__amdgpu_buffer_rsrc_t r, uint32_t
 #define HCT_EPI_CACHE_POLICY 2  /* nt */
 #endif
 constexpr int kNT = HCT_EPI_CACHE_POLICY;
+#ifndef HCT_BF16_OUT_POLICY
+#define HCT_BF16_OUT_POLICY HCT_EPI_CACHE_POLICY  /* bf16 outputs (qkv, GELU(u), dgrads): nt 40.15 ms per step, sc1 40.93, write-back 41.15 */
+#endif
 #ifndef HCT_RES_POLICY
 #define HCT_RES_POLICY 16  /* the fp32 residual-stream output, read back by the next LayerNorm: sc1 39.76 / write-back 39.77 / nt 39.84 ms per step */
 #endif
@@ -644,7 +647,7 @@ __device__ __forceinline__ void epilogue_wave64x128_m(const Epilogue& e, const T
             cs1 += ok ? x1 : f32x4{0, 0, 0, 0};
           }
         }
-        __builtin_amdgcn_raw_buffer_store_b128(pack(x0, x1), tb.c, vc, sc, kNT);
+        __builtin_amdgcn_raw_buffer_store_b128(pack(x0, x1), tb.c, vc, sc, HCT_BF16_OUT_POLICY);
         HCT_STORE_GUARD();
       } else {
         const f32x4 v = *reinterpret_cast<const f32x4*>(patch + pr * 512 + ((cc ^ (pr & 7)) << 4));
@@ -778,7 +781,7 @@ __device__ __forceinline__ void epilogue_wave64x128_h(const Epilogue& e, const T
             cs[h][1] += ok ? x1 : f32x4{0, 0, 0, 0};
           }
         }
-        __builtin_amdgcn_raw_buffer_store_b128(pack(x0, x1), tb.c, vc, sc, kNT);
+        __builtin_amdgcn_raw_buffer_store_b128(pack(x0, x1), tb.c, vc, sc, HCT_BF16_OUT_POLICY);
         HCT_STORE_GUARD();
       } else {
         const f32x4 v = *reinterpret_cast<const f32x4*>(patch + pr * 256 + ((cc ^ pr) << 4));
