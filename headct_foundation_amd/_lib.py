@@ -56,6 +56,7 @@ _PROTOS = {
     "hct_version": (c_int, []),
     "hct_has_mfma_kernels": (c_int, []),
     "hct_gemm_workspace_bytes": (c_size_t, [C.POINTER(GemmArgs)]),
+    "hct_gemm_nt_flags_offset": (c_size_t, [c_size_t]),
     "hct_set_cu_reserve": (None, [c_int]),
     "hct_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p, c_size_t, c_void_p]),
     "hct_mask_rank": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

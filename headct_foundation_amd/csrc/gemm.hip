@@ -829,13 +829,27 @@ __device__ uint32_t g_stamp_words = 0;  // capacity of the stamp buffer: the onl
 #define HCT_STAMP(k)
 #endif
 
+// stream-K region of the NT workspace (its LAST kSkBytes): [flags: one word per workgroup | error word] then one 256-KiB slab of
+// raw fp32 accumulators per workgroup
+constexpr int kSkMaxWgs = 256;
+constexpr size_t kSkHeadBytes = 4096, kSkSlabBytes = 262144;
+constexpr size_t kSkBytes = kSkHeadBytes + (size_t)kSkMaxWgs * kSkSlabBytes;
+constexpr int kSkErrWord = 512;
+
+__device__ __forceinline__ uint32_t xcc_id() {  // the XCD (accelerator die) this wave runs on
+  uint32_t v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 15;
+}
+
 // PERSISTENT: grid = min(tiles, #CUs); each workgroup walks tiles vb = blockIdx.x, +gridDim.x, ... (same XCD every trip,
 // consecutive tiles of an XCD share an A row-panel).  At the end of a tile the first pair of stages of the NEXT tile is
 // issued before the epilogue, so the output stores (asynchronous) and the next tile's HBM latency drain under each other
 // and under the next main loop instead of leaving the CU's matrix pipes idle.
-template <int MODE>
+template <int MODE, bool SK = false>
 __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, int K, const bf16* __restrict__ A, int64_t lda,
-                                                                 const bf16* __restrict__ B, int64_t ldb, Epilogue e, int ntiles, int stagger) {
+                                                                 const bf16* __restrict__ B, int64_t ldb, Epilogue e, int ntiles, int stagger,
+                                                                 int sk_tiles, int sk_wgs, unsigned char* __restrict__ sk_ws, unsigned sk_seq) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[163840];  // 5 stages x (A 16K | B 16K); stage 4 (generic epilogue: 3 and 4) doubles as the epilogue patches
   // Specialised epilogues: the next tile's first TWO stage pairs (ring buffers 0 .. 3) are issued before the epilogue, whose
   // patches are 4 KiB per wave (buffer 4).  The next main loop then waits only for those pairs -- `vmcnt(kEpiOps)`: vector-memory
@@ -846,9 +860,10 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
 #define HCT_NT_TWO_PAIR_MODES 0  /* measured: 0x7E (all specialised modes) +0.37 ms per step, 0x2A (the modes without epilogue loads) the same */
 #endif
   constexpr bool kTwoPairs = MODE != EPI_GENERIC && ((HCT_NT_TWO_PAIR_MODES >> MODE) & 1);
+  static_assert(!(SK && kTwoPairs), "stream-K items assume one prefetched pair");
   constexpr int kEpiOps = EpiTraits<MODE>::ops_per_tile > 63 ? 63 : EpiTraits<MODE>::ops_per_tile;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ntm = (M + 255) >> 8, ntn = (N + 255) >> 8;
+  const int ntn = (N + 255) >> 8;
   float* const colsum_out = e.colsum_partial;  // by value: indexing through `e` made hipcc keep a copy of the struct in scratch
 
   // staging: 1 KiB piece = 16 rows x 64 B; wave w moves pieces 2w, 2w+1 of A and of B each stage
@@ -869,17 +884,21 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
   i32x4 ra, rb;
   const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
   int m0 = 0, n0 = 0;
-  auto set_tile = [&](int vb) {
-    const int nwg = ntm * ntn;
-    const int xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
-    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+  // item = (tile id, first K-stage): the operand descriptors are rooted at (m0 | n0, s0 * 32), the stage offsets stay relative
+  auto set_tile_id = [&](int id, int s0) {
     const int tm = id / ntn, tn = id - tm * ntn;
     m0 = tm << 8;
     n0 = tn << 8;
-    const bf16* Ab = A + (int64_t)m0 * lda;
-    const bf16* Bb = B + (int64_t)n0 * ldb;
-    ra = make_srd(Ab, clamp_records(((int64_t)(M - m0 - 1) * lda + K) * 2));
-    rb = make_srd(Bb, clamp_records(((int64_t)(N - n0 - 1) * ldb + K) * 2));
+    const bf16* Ab = A + (int64_t)m0 * lda + s0 * 32;
+    const bf16* Bb = B + (int64_t)n0 * ldb + s0 * 32;
+    ra = make_srd(Ab, clamp_records(((int64_t)(M - m0 - 1) * lda + K - s0 * 32) * 2));
+    rb = make_srd(Bb, clamp_records(((int64_t)(N - n0 - 1) * ldb + K - s0 * 32) * 2));
+  };
+  // whole tiles: ids [sk_tiles, ntiles), walked vb = blockIdx.x, +gridDim.x, ... through the XCD-contiguous permutation
+  auto dp_id = [&](int vb) {
+    const int nwg = ntiles - sk_tiles;
+    const int xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
+    return sk_tiles + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
   };
   // Stages are fetched in PAIRS (t even, t+1).  One stage is 32 bf16 = 64 B of every row, i.e. half a 128-B line, and a
   // stream of half-line requests draws only 62 GB/s per CU from L2 where whole lines give 111 (scripts/micro/
@@ -960,8 +979,75 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
   uint32_t stamps = 0;
   int tile_i = 0;
 #endif
+  // ---- work items ---------------------------------------------------------------------------------------------------------
+  // Whole tiles cost the same, so ntiles = R * grid + rem leaves (grid - rem) CUs idle for a whole tile time in the last round
+  // (651 tiles of the decoder's N = 768 GEMMs on 256 CUs: 2.54 rounds of work in 3).  In the SK instances the first `sk_tiles`
+  // (= rem) tile ids are therefore shared out by K range ("stream-K" for the remainder, whole tiles for the rest): in units of
+  // stage pairs the rem * P pairs are cut into sk_wgs contiguous ranges, workgroup c takes [bound(c), bound(c+1)), split at the
+  // tile boundary into at most one piece that starts inside a tile (FOLLOWER: raw accumulators to slab c, then flag c) and one
+  // that starts a tile (OWNER: after its own K range it adds the followers' slabs in workgroup order -- a fixed
+  // order, bit-reproducible -- and runs the epilogue).  A follower piece is always the FIRST thing its workgroup does and
+  // never waits, so an owner only ever waits for work that started at kernel start on a higher-numbered workgroup: no
+  // cycles, and a bounded spin flags an error instead of hanging should the grid not be resident.
+  // An item is one packed word -- tile id [0,8) | first pair [8,18) | pairs [18,28) | followers to collect [28,31) -- so that
+  // the persistent loop carries two more scalars than the plain instances, not ten.
+  const int P = nk >> 1;  // stage pairs per tile
+  uint32_t it_first = 0, it_owner = 0;
+  // Owner and followers of a tile sit on the SAME XCD (workgroups are dealt round-robin: XCD = blockIdx & 7): XCD x shares out
+  // its own slice of the remainder tiles over its own workgroups j = blockIdx >> 3, so a follower's slab is read back from the
+  // L2 it was written through, not from HBM.  (Only the speed depends on that placement: stores and flags are agent-scope.)
+  if (SK) {
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int t0 = (x * sk_tiles) >> 3, nx = (((x + 1) * sk_tiles) >> 3) - t0;  // this XCD's tiles [t0, t0 + nx)
+    const int wx = sk_wgs < nx * 4 ? sk_wgs : nx * 4;                           // its workgroups that take a K range (<= 4 per tile)
+    if (j < wx) {
+      auto sk_bound = [&](int c) -> int {
+        if (c >= wx) return nx * P;
+        const int v = (int)(((int64_t)c * nx * P) / wx);
+        const int r = v % P;  // no piece shorter than two pairs (the pipeline needs four stages): snap to the tile boundary
+        return r == 1 ? v - 1 : (r == P - 1 ? v + 1 : v);
+      };
+      int b = sk_bound(j);
+      const int en = sk_bound(j + 1);
+      int t = b / P;
+      const int off = b - t * P;
+      if (off) {
+        const int pe = en < (t + 1) * P ? en : (t + 1) * P;
+        it_first = (uint32_t)(t0 + t) | ((uint32_t)off << 8) | ((uint32_t)(pe - b) << 18);
+        b = pe;
+        ++t;
+      }
+      if (b < en) {  // b == t * P: this workgroup starts tile t; the host keeps every range shorter than a tile
+        const int tend = (t + 1) * P;
+        uint32_t nf = 0;
+        for (int c2 = j + 1; c2 < wx && sk_bound(c2) < tend; ++c2) ++nf;
+        it_owner = (uint32_t)(t0 + t) | ((uint32_t)((en < tend ? en : tend) - b) << 18) | (nf << 28) | 0x80000000u;  // (bit 31: present)
+      }
+      if (!it_first) { it_first = it_owner; it_owner = 0; }
+    }
+  }
   int vb = blockIdx.x;
-  set_tile(vb);
+  uint32_t cit = 0;  // the item set_tile_id was last called for
+  auto take_item = [&](uint32_t it) {
+    set_tile_id((int)(it & 255), (int)((it >> 8) & 1023) * 2);
+    cit = it;
+  };
+  auto next_item = [&]() -> bool {
+    if (SK && it_owner) {
+      take_item(it_owner);
+      it_owner = 0;
+      return true;
+    }
+    if (vb < ntiles - sk_tiles) {
+      set_tile_id(dp_id(vb), 0);
+      cit = (uint32_t)P << 18;
+      vb += gridDim.x;
+      return true;
+    }
+    return false;
+  };
+  if (SK && it_first) take_item(it_first);
+  else if (!next_item()) return;  // (only with stream-K: more workgroups than K ranges and no whole tiles)
   stage_pair(0);
   if (kTwoPairs) {
     stage_pair(2);
@@ -969,7 +1055,9 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
   }
   while (true) {
     HCT_STAMP(0);
-    const int cm0 = m0, cn0 = n0;  // tile being computed (set_tile below moves m0/n0 to the next one)
+    const int cm0 = m0, cn0 = n0;  // item being computed (next_item below moves m0/n0 to the next one)
+    const uint32_t item = cit;
+    const int cns = SK ? (int)((item >> 18) & 1023) * 2 : nk;  // stages of this item
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -993,7 +1081,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     // previous odd step).  Odd step t+1: pair (t+2, t+3), issued two steps ago, must have landed; every wave is then past
     // its reads of stages t-1 and t, whose buffers take pair (t+4, t+5).
     int t = 0;
-    for (; t + 5 < nk; t += 2) {
+    for (; t + 5 < cns; t += 2) {
       rd_b(t, 1, b_hi);
       mma(0, a0, b_lo);
       rd_a(t + 1, a1);
@@ -1007,7 +1095,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
       rd_b(t + 2, 0, b_lo);
       mma(1, a1, b_hi);
     }
-    // t == nk - 4: every stage has been issued
+    // t == cns - 4: every stage of the item has been issued
     rd_b(t, 1, b_hi);
     mma(0, a0, b_lo);
     rd_a(t + 1, a1);
@@ -1015,7 +1103,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     mma(1, a0, b_hi);
     rd_b(t + 1, 1, b_hi);
     mma(0, a1, b_lo);
-    land_first(t);  // pair (nk-2, nk-1)
+    land_first(t);  // pair (cns-2, cns-1)
     rd_a(t + 2, a0);
     rd_b(t + 2, 0, b_lo);
     mma(1, a1, b_hi);
@@ -1044,14 +1132,70 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
         else asm volatile("" : "+v"(bh[h].lo));
       }
     }
-    vb += gridDim.x;
-    const bool more = vb < ntiles;
-    if (more) {  // prefetch the next tile's first pair(s) of stages (ring buffers 0, 1 [, 2, 3]) under this tile's epilogue
-      set_tile(vb);
+    const bool more = next_item();
+    if (more) {  // prefetch the next item's first pair(s) of stages (ring buffers 0, 1 [, 2, 3]) under this item's epilogue
       stage_pair(0);
       if (kTwoPairs) stage_pair(2);
     }
-    {
+    if (SK && ((item >> 8) & 1023)) {
+      // FOLLOWER piece: the raw accumulators leave in register order (1 KiB per store instruction), write-through (sc1) like
+      // the wgrad's split partials -- a write-through store needs no release fence -- then ONE flag per workgroup
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(sk_ws + kSkHeadBytes + (size_t)blockIdx.x * kSkSlabBytes, 0, (uint32_t)kSkSlabBytes, 0x00020000);
+      int ln = lane;
+      asm volatile("" : "+v"(ln));  // (not hoisted out of the persistent loop: a register there costs a spill in the main loop)
+      const uint32_t off0 = (uint32_t)(wave * 32768 + ln * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, off0 + (uint32_t)((i * 8 + j) * 1024), 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0)  // flag = launch sequence number | the XCD this workgroup really runs on
+        __hip_atomic_store((unsigned*)sk_ws + blockIdx.x, (sk_seq << 4) | xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (SK && ((item >> 28) & 7)) {
+        // OWNER of a shared tile: add the followers' partials, workgroup order c+1, c+2, ...  Their bytes were stored
+        // write-through and drained before the flag; the poll is relaxed, ONE agent-scope acquire then drops this CU's stale
+        // lines before the plain loads (the protocol of the wgrad's in-launch fold; MI355X_MICROARCH.md, "Valid forms").
+        const int c_end = (int)blockIdx.x + 8 * (1 + (int)((item >> 28) & 7));
+        for (int c2 = blockIdx.x + 8; c2 < c_end; c2 += 8) {  // the next workgroups of this XCD
+          if (threadIdx.x == 0) {
+            unsigned spins = 0, f;
+            while (((f = __hip_atomic_load((unsigned*)sk_ws + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 4) != (sk_seq & 0x0FFFFFFFu) &&
+                   spins < (1u << 20)) {
+              __builtin_amdgcn_s_sleep(8);
+              ++spins;
+            }
+            if (spins >= (1u << 20))  // cannot happen with a resident grid: flag it (hct_gemm_nt_flags_offset) instead of hanging the GPU
+              __hip_atomic_store((unsigned*)sk_ws + kSkErrWord, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // Same XCD (the rule, see the item set-up): the slab was written THROUGH this XCD's L2 and is read below by loads that
+            // bypass the vector L1 (sc1), so nothing has to be invalidated.  Another XCD: agent-scope acquire first -- it drops the
+            // L2's clean lines, the operand panels of all 32 CUs with them, which is why it is not done unconditionally.
+            if ((f & 15) != xcc_id()) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          }
+          __syncthreads();
+          const __amdgpu_buffer_rsrc_t rs =
+              __builtin_amdgcn_make_buffer_rsrc(sk_ws + kSkHeadBytes + (size_t)c2 * kSkSlabBytes, 0, (uint32_t)kSkSlabBytes, 0x00020000);
+          int ln = lane;
+          asm volatile("" : "+v"(ln));
+          const uint32_t off0 = (uint32_t)(wave * 32768 + ln * 16);
+#pragma unroll
+          for (int i = 0; i < 4; i += 2) {  // 16 loads (16 KiB per wave) in flight: the fragment registers are dead here
+            f32x4 v[2][8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                v[u][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off0 + (uint32_t)(((i + u) * 8 + j) * 1024), 0, 16));
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[i + u][j] += v[u][j];
+          }
+        }
+      }
       // generic: ring buffers 3 and 4 (8 KiB per wave), refilled only after the next tile's first barrier; specialised: buffer 4
       unsigned char* patch = kTwoPairs ? smem + 4 * 32768 + wave * 4096 : smem + 3 * 32768 + wave * 8192;
       if (MODE == EPI_GENERIC) {
@@ -1754,6 +1898,28 @@ static int epilogue_mode(const hct_gemm_args* a) {
   return EPI_GENERIC;
 }
 
+// Stream-K for the remainder round of the persistent 256x256 NT kernel.  What it saves is the idle share of the last round, in
+// stage pairs per CU; what it costs is one 256-KiB slab out and one or two in per workgroup, a second pipeline fill, and the
+// clock / bandwidth head-room that the idle CUs were leaving to the busy ones.  Measured inside the training step
+// (scripts/ab_step.py sk20 / sk16 / skoff): a threshold of 20 pairs -- the decoder's K = 3072 GEMMs with 651 tiles, 22 pairs
+// saved -- is 0.23 ms per step faster than whole tiles; 16 (adds the encoder's 165-tile K = 3072 and the decoder's K = 2304
+// GEMMs) is 0.10 ms slower, 8 is 0.3 ms slower.
+static int g_sk_min_k = 512;       // debug hook: hct_debug_set_gemm_variant(-1000 - k); k > any K switches stream-K off
+static int g_sk_gain_pairs = 20;   // debug hook: hct_debug_set_gemm_variant(-100 - n)
+static bool nt_stream_k(const hct_gemm_args* a, int tiles256, int& sk_tiles, int& sk_wgs) {
+  sk_tiles = sk_wgs = 0;
+  const int G = num_cus(), P = a->K / 64;
+  if ((HCT_NT_TWO_PAIR_MODES) != 0 || G > kSkMaxWgs || a->K < g_sk_min_k || P < 8 || P > 1023) return false;
+  const int rem = tiles256 % G;  // (< 256: fits the packed item's tile field)
+  if (rem == 0 || (int64_t)(G - rem) * P < (int64_t)g_sk_gain_pairs * G) return false;
+  // per XCD (grid / 8 workgroups, ceil(rem / 8) tiles at most): every K range at least four pairs long and shorter than a tile
+  const int gx = G / 8, nxmax = (rem + 7) / 8;
+  if (G % 8 || (int64_t)nxmax * P > (int64_t)gx * (P - 1)) return false;
+  sk_tiles = rem;
+  sk_wgs = (int)std::min<int64_t>(gx, std::max<int64_t>(1, (int64_t)(rem / 8) * P / 4));  // workgroups per XCD that may take a K range
+  return true;
+}
+
 static void tn_split(const hct_gemm_args* a, int& splits, int& r_chunk) {
   const int tiles = ((a->M + 127) / 128) * ((a->N + 127) / 128);
   const int steps = (a->K + 63) / 64;
@@ -1775,6 +1941,8 @@ extern "C" {
 void hct_set_cu_reserve(int n) { g_cu_reserve = n < 0 ? 0 : n; }
 void hct_debug_set_gemm_variant(int v) {
   if (v == -4 || v == -5) { g_w4_auto = v == -4; return; }
+  if (v <= -1000) { g_sk_min_k = -v - 1000; return; }       // stream-K of the NT remainder round only for K >= this (huge: off)
+  if (v <= -100) { g_sk_gain_pairs = -v - 100; return; }     // ... and only where it saves at least this many stage pairs per CU
   if (v == -6 || v == -7) { g_tn_separate_fold = v == -6; return; }  // -6 / -7: separate fold kernel for the wgrad splits on / off  // -4 / -5: auto-dispatch of the 2-WG/CU variant on / off
   g_nt_variant = v;
 }
@@ -1792,7 +1960,12 @@ static size_t colsum_ws(const hct_gemm_args* a) {
   return std::max(fused, hct_colsum_workspace_bytes(a->M, a->N));
 }
 
+static size_t colsum_ws256(const hct_gemm_args* a) { return (colsum_ws(a) + 255) & ~(size_t)255; }
+
 size_t hct_gemm_workspace_bytes(const hct_gemm_args* a) {
+  // NT: column-sum partials (if asked for) at the head; the stream-K region of the persistent kernel at the tail (optional: a
+  // caller that passes less, or no workspace, gets whole tiles only)
+  if (choose_path(a) == PATH_NT) return a->K % 64 == 0 && a->K >= 512 ? colsum_ws256(a) + kSkBytes : colsum_ws(a);
   if (choose_path(a) != PATH_TN) return colsum_ws(a);
   int splits, r_chunk;
   if (tn256_ok(a)) {
@@ -1801,6 +1974,10 @@ size_t hct_gemm_workspace_bytes(const hct_gemm_args* a) {
   }
   tn_split(a, splits, r_chunk);
   return splits > 1 ? (size_t)splits * a->M * a->N * sizeof(float) : 0;
+}
+
+size_t hct_gemm_nt_flags_offset(size_t workspace_bytes) {
+  return workspace_bytes >= kSkBytes ? ((workspace_bytes - kSkBytes) & ~(size_t)255) : (size_t)-1;
 }
 
 int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, void* stream) {
@@ -1822,7 +1999,9 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
   auto finish_colsum = [&](bool fused) -> int {
     if (!a->colsum_out) return 0;
     if (fused) return fold_rows((const float*)workspace, ((a->M + 255) / 256) * 4, a->N, a->colsum_out, s);
-    return hct_colsum(a->C, a->c_dtype, a->M, a->N, a->ldc, a->colsum_out, workspace, workspace_bytes, stream);
+    // (the tail of a workspace that is large enough for it belongs to the stream-K flags and slabs)
+    const size_t head = workspace_bytes >= colsum_ws256(a) + kSkBytes ? ((workspace_bytes - kSkBytes) & ~(size_t)255) : workspace_bytes;
+    return hct_colsum(a->C, a->c_dtype, a->M, a->N, a->ldc, a->colsum_out, workspace, head, stream);
   };
   const double flops = 2.0 * a->M * a->N * a->K;
   // algorithmic bytes: each operand read once, each output written once (SURVEY 8d secondary report)
@@ -1866,15 +2045,33 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
       //  wave's 64 rows lie wholly past M -- so the fixed-order fold over ceil(M / 256) * 4 rows sees no stale data)
       const bool fuse_cs = a->colsum_out && mode == EPI_DGELU_BF16 && !w4;
       if (fuse_cs) e.colsum_partial = (float*)workspace;
-      const dim3 grid(std::min(tiles256, num_cus()));
+      // stream-K for the remainder round (see the kernel): needs its region at the END of the workspace
+      int sk_tiles = 0, sk_wgs = 0;
+      unsigned char* sk_ws = nullptr;
+      unsigned sk_seq = 0;
+      if (workspace && workspace_bytes >= colsum_ws256(a) + kSkBytes && nt_stream_k(a, tiles256, sk_tiles, sk_wgs)) {
+        sk_ws = (unsigned char*)workspace + ((workspace_bytes - kSkBytes) & ~(size_t)255);
+        static unsigned seq = 0;
+        sk_seq = (++seq) & 0x0FFFFFFFu;  // (28 bits: the flag word also carries the writer's XCD)
+        if (sk_seq == 0) sk_seq = (++seq) & 0x0FFFFFFFu;  // zero is what an armed region starts from
+        if (!a->workspace_armed)
+          if (int rc = check_hip(hipMemsetAsync(sk_ws, 0, kSkHeadBytes, s), "hct_gemm(nt256): stream-K flag reset")) return rc;
+      }
+      const dim3 grid(sk_tiles ? num_cus() : std::min(tiles256, num_cus()));
       // one start phase = 1/8 of a tile's main loop (nk stages x ~1000 cycles; s_sleep(32) = 2048 cycles); only when each
       // CU runs several tiles (otherwise the delay is pure loss)
       // (a start-phase stagger of the workgroups helped the earlier one-stage-per-step schedule by ~0.1 ms per step; with
       //  the paired schedule it is neutral to slightly negative: off unless forced through the debug hook)
       const int stagger = g_stagger >= 0 ? g_stagger : 0;
-#define HCT_NT256(MODE_)                                                                                              \
-  hipLaunchKernelGGL(gemm_bf16_nt256_kernel<MODE_>, grid, dim3(512), 0, s, a->M, a->N, a->K, (const bf16*)a->A, a->lda, \
-                     (const bf16*)a->B, a->ldb, e, tiles256, stagger)
+#define HCT_NT256(MODE_)                                                                                                       \
+  do {                                                                                                                         \
+    if (sk_tiles)                                                                                                              \
+      hipLaunchKernelGGL((gemm_bf16_nt256_kernel<MODE_, (HCT_NT_TWO_PAIR_MODES) == 0>), grid, dim3(512), 0, s, a->M, a->N, a->K, \
+                         (const bf16*)a->A, a->lda, (const bf16*)a->B, a->ldb, e, tiles256, stagger, sk_tiles, sk_wgs, sk_ws, sk_seq); \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((gemm_bf16_nt256_kernel<MODE_, false>), grid, dim3(512), 0, s, a->M, a->N, a->K, (const bf16*)a->A,     \
+                         a->lda, (const bf16*)a->B, a->ldb, e, tiles256, stagger, 0, 0, (unsigned char*)nullptr, 0u);             \
+  } while (0)
       switch (mode) {
         case EPI_PLAIN_BF16: HCT_NT256(EPI_PLAIN_BF16); break;
         case EPI_RES_F32: HCT_NT256(EPI_RES_F32); break;

@@ -54,7 +54,7 @@ struct hct_mae_plan {
       a_ynorm, a_yn_mean, a_yn_rstd, a_pred, a_dpred;
   std::vector<size_t> h_enc, h_dec;  // fp32 residual-stream chain
   std::vector<BlockA> aenc, adec;
-  size_t s_dh, s_dh_shadow, s_dbig, s_dx, s_do, s_dqkv, s_small, s_small_bytes, s_gemm, s_gemm_bytes;
+  size_t s_dh, s_dh_shadow, s_dbig, s_dx, s_do, s_dqkv, s_small, s_small_bytes, s_gemm, s_gemm_bytes, s_nt_bytes = 0;
   std::map<std::string, Act> acts;
   // bound buffers
   float* params_f32 = nullptr;
@@ -64,6 +64,7 @@ struct hct_mae_plan {
   unsigned char* ws = nullptr;
   bool fwd_done = false;
   bool gemm_ws_armed = false;
+  bool nt_ws_armed = false;  // the stream-K tail of [s_small | s_nt] has been zeroed since the last bind
   bool dpred_done = false;  // the last forward also wrote d(loss)/d(pred) (training forward)
   const float* dloss = nullptr;
 
@@ -210,6 +211,19 @@ hct_gemm_args base_args() {
   return a;
 }
 
+// Workspace of the forward / dgrad GEMMs: [s_small (column-sum partials) | stream-K region of the persistent NT kernel].  The
+// two regions are adjacent in the plan's layout and the kernel takes its region from the END of what it is given, so its flags
+// always sit at the same address, which nothing else writes; zeroed by the first GEMM after a bind.
+int nt_gemm(hct_mae_plan* p, hct_gemm_args& a, hipStream_t s) {
+  if (p->s_nt_bytes == 0) return hct_gemm(&a, a.colsum_out ? p->ws + p->s_small : nullptr, a.colsum_out ? p->s_small_bytes : 0, s);
+  if (!p->nt_ws_armed) {
+    if (hipMemsetAsync(p->ws + p->s_small + p->s_small_bytes, 0, p->s_nt_bytes, s) != hipSuccess) return HCT_E_WORKSPACE;
+    p->nt_ws_armed = true;
+  }
+  a.workspace_armed = 1;
+  return hct_gemm(&a, p->ws + p->s_small, p->s_small_bytes + p->s_nt_bytes, s);
+}
+
 // Y[M,N] = act(X[M,K] . W[N,K]^T + b) (+ residual)
 int linear_fwd(hct_mae_plan* p, const void* X, int M, int K, int w, int b, int N, void* Y, int y_dtype, int act, void* aux,
                const float* residual, hipStream_t s) {
@@ -221,7 +235,7 @@ int linear_fwd(hct_mae_plan* p, const void* X, int M, int K, int w, int b, int N
   a.bias = p->pf(b);
   a.residual = residual; a.ldr = N;
   a.act = act; a.aux = aux; a.aux_dtype = p->dt; a.ldaux = N;
-  return hct_gemm(&a, nullptr, 0, s);
+  return nt_gemm(p, a, s);
 }
 
 // dX[M,K] = dY[M,N] . W[N,K]   (optionally * gelu'(aux))
@@ -235,8 +249,7 @@ int linear_dgrad(hct_mae_plan* p, const void* dY, int M, int N, int w, int K, vo
   else { a.B = p->wop(w); a.b_dtype = HCT_F32; a.ldb = K; a.transB = 0; }
   a.C = dX; a.c_dtype = p->dt; a.ldc = K;
   a.act = act; a.aux = aux; a.aux_dtype = p->dt; a.ldaux = K;
-  if (colsum_out) return hct_gemm(&a, p->ws + p->s_small, p->s_small_bytes, s);
-  return hct_gemm(&a, nullptr, 0, s);
+  return nt_gemm(p, a, s);
 }
 
 // dW[N,K] = dY[M,N]^T . X[M,K]  (fp32 gradient); optional bias gradient = colsum(dY)
@@ -436,8 +449,17 @@ hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int comput
   small = std::max(small, hct_colsum_workspace_bytes((int)Mx, (int)mlpx));
   small = std::max(small, hct_colsum_workspace_bytes((int)Md, p->pd));
   small = std::max(small, (size_t)((Mx + 255) / 256) * 4 * mlpx * sizeof(float));  // fused colsum partials of the dGELU dgrad
+  small = align_up(small, 256);
   p->s_small_bytes = small;
   p->s_small = w.take(small);
+  if (p->dt == HCT_BF16) {  // stream-K region of the persistent NT GEMM, directly behind s_small (see nt_gemm)
+    hct_gemm_args a = base_args();
+    a.M = 256; a.N = 256; a.K = 512;
+    a.a_dtype = a.b_dtype = a.c_dtype = HCT_BF16; a.lda = a.ldb = 512; a.ldc = 256; a.transA = 0; a.transB = 1;
+    a.A = (const void*)256; a.B = (const void*)256; a.C = (void*)256;  // alignment probes only
+    p->s_nt_bytes = hct_gemm_workspace_bytes(&a);
+    w.take(p->s_nt_bytes);
+  }
   size_t gw = 0;
   for (int side = 0; side < 2; ++side) {
     const int M = side ? p->Md : p->Me, d = side ? p->Dd : p->D, m = side ? p->Mlpd : p->Mlp;
@@ -495,6 +517,7 @@ int hct_mae_plan_bind(hct_mae_plan* p, float* params, float* grads, void* params
   p->params_bf16 = (bf16*)params_bf16; p->params_bf16_t = (bf16*)params_bf16_t;
   p->ws = (unsigned char*)workspace;
   p->gemm_ws_armed = false;
+  p->nt_ws_armed = false;
   p->fwd_done = false;
   return 0;
 }

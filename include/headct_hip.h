@@ -75,10 +75,20 @@ typedef struct hct_gemm_args {
   float* colsum_out;     /* optional [N] fp32: column sums of the OUTPUT C (the bias gradient of the Linear that produced the
                             operand of this dgrad); fused into the epilogue where the kernel supports it */
   int workspace_armed;   /* wgrad split fold: 1 = the first 1 KiB of `workspace` was zero when first used and has only been
-                            touched by hct_gemm since (its counters re-arm themselves): skips the per-call reset.  0 = reset it. */
+                            touched by hct_gemm since (its counters re-arm themselves): skips the per-call reset.  0 = reset it.
+                            NT path: the same promise for the head of the stream-K region (hct_gemm_nt_flags_offset). */
 } hct_gemm_args;
 
 size_t hct_gemm_workspace_bytes(const hct_gemm_args* a);
+/* NT path (forward Linears / dgrads), persistent 256x256 kernel: when the tile count leaves a partly filled last round, the
+ * remainder tiles are shared out by K range over all CUs ("stream-K"; whole tiles for the rest), partial accumulators passing
+ * through the LAST 64 MiB + 4 KiB of `workspace` in a fixed summation order (bit-reproducible).  Optional: with a smaller (or
+ * no) workspace the launch uses whole tiles only.  hct_gemm_nt_flags_offset = byte offset of that region's head inside a
+ * workspace of the given size ((size_t)-1: too small): 256 32-bit arrival flags, and at byte 2048 an error word that a launch
+ * sets to 0xDEAD if a partial never arrived (cannot happen while the grid is resident; it is flagged rather than waited for).
+ * The head is reset before every such launch unless `workspace_armed` says that it started zeroed and only hct_gemm has
+ * written it since. */
+size_t hct_gemm_nt_flags_offset(size_t workspace_bytes);
 /* Leave `n` CUs out of the persistent GEMM grids (default 0) so that communication kernels (RCCL all-reduce overlapped
  * with the backward) have somewhere to run; set by the data-parallel wrapper when world_size > 1. */
 void hct_set_cu_reserve(int n);

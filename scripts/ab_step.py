@@ -30,6 +30,12 @@ HOOKS = {
     "fwd4": (lambda: lib.hct_debug_force_simple_attention(100062), lambda: lib.hct_debug_force_simple_attention(100054)),  # on = persistent forward for the decoder
     "stagger2": (lambda: lib.hct_debug_set_gemm_stagger(2), lambda: lib.hct_debug_set_gemm_stagger(-1)),
     "stagger4": (lambda: lib.hct_debug_set_gemm_stagger(4), lambda: lib.hct_debug_set_gemm_stagger(-1)),
+    "skoff": (lambda: lib.hct_debug_set_gemm_variant(-1000 - (1 << 24)), lambda: lib.hct_debug_set_gemm_variant(-1000 - 512)),  # on = whole tiles only (no stream-K remainder round)
+    "sk1536": (lambda: lib.hct_debug_set_gemm_variant(-1000 - 1536), lambda: lib.hct_debug_set_gemm_variant(-1000 - 512)),  # on = stream-K only for K >= 1536
+    "skgain8": (lambda: lib.hct_debug_set_gemm_variant(-100 - 8), lambda: lib.hct_debug_set_gemm_variant(-100 - 20)),  # on = stream-K where it saves >= 8 pairs per CU (default 20)
+    # on = stream-K where it saves >= 20 / 16 stage pairs per CU, off = whole tiles only
+    "sk20": (lambda: (lib.hct_debug_set_gemm_variant(-1000 - 512), lib.hct_debug_set_gemm_variant(-100 - 20)), lambda: lib.hct_debug_set_gemm_variant(-1000 - (1 << 24))),
+    "sk16": (lambda: (lib.hct_debug_set_gemm_variant(-1000 - 512), lib.hct_debug_set_gemm_variant(-100 - 16)), lambda: lib.hct_debug_set_gemm_variant(-1000 - (1 << 24))),
     "none": (lambda: None, lambda: None),
 }
 name = sys.argv[1] if len(sys.argv) > 1 else "none"

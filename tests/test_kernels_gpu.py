@@ -84,6 +84,89 @@ def test_gemm_nt_bf16_mfma(lib, cuda, M, N, K):
     assert rel_err(dy, (A.float() @ B.float().t()) * u.grad) < 4e-3
 
 
+def _nt_call(lib, A, B, M, N, K, ws, out_dtype, bias=None, residual=None, act=0, aux=None, colsum=None, armed=0):
+    Cm = torch.empty(M, N, dtype=out_dtype, device=A.device)
+    a = GemmArgs()
+    a.M, a.N, a.K = M, N, K
+    a.A, a.a_dtype, a.lda, a.transA = A.data_ptr(), _dt(A), K, 0
+    a.B, a.b_dtype, a.ldb, a.transB = B.data_ptr(), _dt(B), K, 1
+    a.C, a.c_dtype, a.ldc = Cm.data_ptr(), _dt(Cm), N
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.residual = residual.data_ptr() if residual is not None else None
+    a.ldr = N
+    a.act = act
+    if aux is not None:
+        a.aux, a.aux_dtype, a.ldaux = aux.data_ptr(), _dt(aux), N
+    a.colsum_out = colsum.data_ptr() if colsum is not None else None
+    a.alpha = 1.0
+    a.workspace_armed = armed
+    assert ws is None or ws.numel() >= lib.hct_gemm_workspace_bytes(C.byref(a))
+    _lib.check(lib.hct_gemm(C.byref(a), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _st()), "hct_gemm")
+    return Cm
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 2048, 1024), (3000, 1008, 1536), (55552, 768, 3072), (55552, 3072, 768), (14080, 768, 2304),
+                                   (2000, 496, 512)])
+def test_gemm_nt_stream_k_remainder(lib, cuda, M, N, K):
+    """Persistent NT kernel with the remainder round shared out by K range: every epilogue instance against the whole-tile
+    schedule (hook -1000-k: stream-K only for K >= k) and against fp32 torch, bit-identical repeats, flags consumed, no timeout.
+    The shapes give 4 (first, last), 6 and ~26 / ~45 stage pairs per K range, ragged M and N, and the step's own worst cases
+    (651 tiles = 2.54 rounds; 2604 tiles = 10.17 rounds)."""
+    A = _rand((M, K), cuda, torch.bfloat16, 11)
+    B = _rand((N, K), cuda, torch.bfloat16, 12, 0.05)
+    bias = _rand((N,), cuda, torch.float32, 13)
+    res = _rand((M, N), cuda, torch.float32, 14)
+    nbytes = (M + 255) // 256 * 4 * N * 4 + (1 << 20) + 64 * 1024 * 1024 + 4096
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=cuda)
+    off = lib.hct_gemm_nt_flags_offset(ws.numel())
+    assert off != 2 ** 64 - 1 and off % 256 == 0
+    flags = ws[off:off + 4096].view(torch.int32)
+    ref = A.float() @ B.float().t()
+
+    def run(armed):
+        out = {}
+        out["plain"] = _nt_call(lib, A, B, M, N, K, ws, torch.bfloat16, armed=armed)
+        out["res"] = _nt_call(lib, A, B, M, N, K, ws, torch.float32, bias=bias, residual=res, armed=armed)
+        aux = torch.empty(M, N, dtype=torch.bfloat16, device=cuda)
+        out["gelu"] = _nt_call(lib, A, B, M, N, K, ws, torch.bfloat16, bias=bias, act=1, aux=aux, armed=armed)
+        out["aux"] = aux
+        out["dgelu"] = _nt_call(lib, A, B, M, N, K, ws, torch.bfloat16, act=2, aux=aux, armed=armed)
+        cs = torch.empty(N, dtype=torch.float32, device=cuda)
+        out["dgelu_cs"] = _nt_call(lib, A, B, M, N, K, ws, torch.bfloat16, act=2, aux=aux, colsum=cs, armed=armed)
+        out["cs"] = cs
+        out["generic"] = _nt_call(lib, A, B, M, N, K, ws, torch.float32, bias=bias, armed=armed)  # fp32 out without residual: runtime-flag epilogue
+        torch.cuda.synchronize()
+        return out
+
+    lib.hct_debug_set_gemm_variant(-1000 - 512)
+    lib.hct_debug_set_gemm_variant(-100 - 1)  # take every remainder round that saves at least one pair
+    try:
+        flags.zero_()
+        sk = run(0)
+        used = int((flags[:256] != 0).sum())
+        assert used > 0, "stream-K did not engage"
+        assert int(flags[512]) == 0, "a partial never arrived"
+        sk2 = run(1)  # armed: no reset between launches, flags carry the previous launches' sequence numbers
+        assert int(flags[512]) == 0
+    finally:
+        lib.hct_debug_set_gemm_variant(-1000 - 512)
+        lib.hct_debug_set_gemm_variant(-100 - 20)
+    lib.hct_debug_set_gemm_variant(-1000 - (1 << 24))
+    try:
+        whole = run(0)
+    finally:
+        lib.hct_debug_set_gemm_variant(-1000 - 512)
+    for k in sk:
+        assert torch.equal(sk[k], sk2[k]), k  # fixed summation order
+    assert rel_err(sk["res"], ref + bias + res) < 1e-5 and rel_err(sk["generic"], ref + bias) < 1e-5
+    assert rel_err(sk["plain"], ref) < 4e-3
+    for k in ("res", "generic"):  # fp32 outputs: the K ranges only reorder the fp32 sums
+        assert rel_err(sk[k], whole[k]) < 1e-6, k
+    for k in ("plain", "gelu", "aux", "dgelu", "dgelu_cs"):  # bf16 outputs: a different summation order may flip a rounding
+        assert rel_err(sk[k], whole[k]) < 2e-3, k
+    assert rel_err(sk["cs"], whole["cs"]) < 1e-4
+
+
 @pytest.mark.parametrize("R,M,N", [(217 * 4, 768, 768), (55 * 5, 2304, 768), (1000, 768, 3072), (64, 192, 192),
                                    (5000, 4096, 768), (33, 48, 64), (130, 576, 192)])
 def test_gemm_tn_bf16_mfma(lib, cuda, R, M, N):
