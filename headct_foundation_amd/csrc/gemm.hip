@@ -14,6 +14,8 @@
 #include "common.h"
 #include "prof.h"
 
+#include <cstdlib>
+
 namespace hct {
 
 static int g_w4_auto = 0;   // auto-dispatch of the 2-WG/CU variant: faster in isolation on the decoder's GELU / +residual
@@ -1905,7 +1907,11 @@ static int epilogue_mode(const hct_gemm_args* a) {
 // saved -- is 0.23 ms per step faster than whole tiles; 16 (adds the encoder's 165-tile K = 3072 and the decoder's K = 2304
 // GEMMs) is 0.10 ms slower, 8 is 0.3 ms slower.
 static int g_sk_min_k = 512;       // debug hook: hct_debug_set_gemm_variant(-1000 - k); k > any K switches stream-K off
-static int g_sk_gain_pairs = 20;   // debug hook: hct_debug_set_gemm_variant(-100 - n)
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+static int g_sk_gain_pairs = env_int("HCT_NT_STREAMK_PAIRS", 20);  // debug hook: hct_debug_set_gemm_variant(-100 - n); a huge value = whole tiles only
 static bool nt_stream_k(const hct_gemm_args* a, int tiles256, int& sk_tiles, int& sk_wgs) {
   sk_tiles = sk_wgs = 0;
   const int G = num_cus(), P = a->K / 64;

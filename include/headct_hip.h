@@ -87,7 +87,8 @@ size_t hct_gemm_workspace_bytes(const hct_gemm_args* a);
  * workspace of the given size ((size_t)-1: too small): 256 32-bit arrival flags, and at byte 2048 an error word that a launch
  * sets to 0xDEAD if a partial never arrived (cannot happen while the grid is resident; it is flagged rather than waited for).
  * The head is reset before every such launch unless `workspace_armed` says that it started zeroed and only hct_gemm has
- * written it since. */
+ * written it since.  Environment: HCT_NT_STREAMK_PAIRS = least number of K-stage pairs per CU the sharing must save for it
+ * to be used (default 20, tuned on the MAE step; a huge value switches it off). */
 size_t hct_gemm_nt_flags_offset(size_t workspace_bytes);
 /* Leave `n` CUs out of the persistent GEMM grids (default 0) so that communication kernels (RCCL all-reduce overlapped
  * with the backward) have somewhere to run; set by the data-parallel wrapper when world_size > 1. */
