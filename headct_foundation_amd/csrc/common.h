@@ -46,6 +46,25 @@ int scale_unless_one(void* buf, int dtype, int64_t n, const float* scale, hipStr
 // out[d] = sum_{b < nblk} partial[b*D + d]  (fixed order; elementwise.hip)
 int fold_rows(const float* partial, int nblk, int D, float* out, hipStream_t s);
 
+// Deferred folds.  The fixed-order folds of per-block partial sums (LayerNorm gamma / beta / column sums, fused bias column
+// sums) are launches of a few dozen workgroups that the NEXT kernel on the stream would have to wait for although it does not
+// read their result.  While a sink is installed (the model driver does so around a block's backward, with a partial buffer of
+// its own for every producer) these folds are recorded instead of launched, and fold_flush() runs them all in ONE launch, each
+// with exactly the summation order of the separate launch.
+struct FoldJob {
+  const float* partial;  // [nblk][nq_stride][D]
+  int nblk, nq_stride, D, nq;
+  float* out[3];         // per quantity q < nq (a null output is skipped)
+};
+struct FoldSink {
+  static constexpr int kMax = 8;
+  FoldJob jobs[kMax];
+  int n = 0;
+};
+extern thread_local FoldSink* g_fold_sink;
+int fold_partials(const FoldJob& job, hipStream_t s);  // into the sink if one is installed (and has room), else launched now
+int fold_flush(FoldSink& sink, hipStream_t s);
+
 inline size_t dtype_size(int dt) { return dt == HCT_BF16 ? 2 : 4; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -598,10 +598,76 @@ __global__ void __launch_bounds__(256) transpose_cast_kernel(const TI* __restric
   }
 }
 
+// several folds in one launch: blockIdx.y walks the (job, quantity) pairs, blockIdx.x the 32-column groups of the widest job
+struct FoldBatch {
+  FoldJob jobs[FoldSink::kMax];
+  int first_y[FoldSink::kMax + 1];
+  int n;
+};
+__global__ void __launch_bounds__(512) fold_batch_kernel(FoldBatch b) {
+  __shared__ float s_red[16][32];
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.y >= b.first_y[j + 1]) ++j;
+  const FoldJob& job = b.jobs[j];
+  const int q = blockIdx.y - b.first_y[j];
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + c;
+  float* out = job.out[q];
+  if (out == nullptr || (int)blockIdx.x * 32 >= job.D) return;  // (uniform over the workgroup)
+  const float* partial = job.partial;
+  const int nblk = job.nblk, nq_stride = job.nq_stride, D = job.D;
+  float acc = 0.f;
+  if (d < D)
+    for (int b0 = rg; b0 < nblk; b0 += 16 * 8) {  // the loop of fold_partials_kernel: same order of additions, same result
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = b0 + 16 * u < nblk ? partial[((size_t)(b0 + 16 * u) * nq_stride + q) * D + d] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (b0 + 16 * u < nblk) acc += v[u];
+    }
+  s_red[rg][c] = acc;
+  __syncthreads();
+  if (rg == 0 && d < D) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += s_red[i][c];
+    out[d] = v;
+  }
+}
+
+thread_local FoldSink* g_fold_sink = nullptr;
+
+int fold_partials(const FoldJob& job, hipStream_t s) {
+  if (g_fold_sink && g_fold_sink->n < FoldSink::kMax) {
+    g_fold_sink->jobs[g_fold_sink->n++] = job;
+    return 0;
+  }
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((job.D + 31) / 32, job.nq), dim3(kFoldThreads), 0, s, job.partial, job.nblk, job.nq_stride,
+                     job.D, job.out[0], job.nq > 1 ? job.out[1] : (float*)nullptr, job.nq > 2 ? job.out[2] : (float*)nullptr);
+  return check_hip(hipGetLastError(), "fold_partials");
+}
+
+int fold_flush(FoldSink& sink, hipStream_t s) {
+  if (sink.n == 0) return 0;
+  FoldBatch b;
+  int y = 0, maxd = 0;
+  for (int i = 0; i < sink.n; ++i) {
+    b.jobs[i] = sink.jobs[i];
+    b.first_y[i] = y;
+    y += sink.jobs[i].nq;
+    maxd = sink.jobs[i].D > maxd ? sink.jobs[i].D : maxd;
+  }
+  for (int i = sink.n; i <= FoldSink::kMax; ++i) b.first_y[i] = y;
+  for (int i = sink.n; i < FoldSink::kMax; ++i) b.jobs[i] = FoldJob{nullptr, 0, 0, 0, 0, {nullptr, nullptr, nullptr}};
+  b.n = sink.n;
+  sink.n = 0;
+  hipLaunchKernelGGL(fold_batch_kernel, dim3((maxd + 31) / 32, y), dim3(kFoldThreads), 0, s, b);
+  return check_hip(hipGetLastError(), "fold_flush");
+}
+
 int fold_rows(const float* partial, int nblk, int D, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(fold_partials_kernel, dim3((D + 31) / 32, 1), dim3(kFoldThreads), 0, s, partial, nblk, 1, D, out, (float*)nullptr,
-                     (float*)nullptr);
-  return check_hip(hipGetLastError(), "fold_rows");
+  return fold_partials(FoldJob{partial, nblk, 1, D, 1, {out, nullptr, nullptr}}, s);
 }
 
 
@@ -972,10 +1038,8 @@ int hct_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
     else rc = launch_ln_bwd<float, float>(dy, x, mean, rstd, gamma, dres, rows, D, dx, dx_shadow, partial, dcolsum != nullptr, nblk, s);
   }
   if (rc) return rc;
-  hipLaunchKernelGGL(fold_partials_kernel, dim3((D + 31) / 32, dcolsum ? 3 : 2), dim3(kFoldThreads), 0, s, partial, nblk, 3, D,
-                     dgamma, dbeta, dcolsum);
   HCT_CHECK_LAUNCH("hct_layernorm_bwd");
-  return 0;
+  return fold_partials(FoldJob{partial, nblk, 3, D, dcolsum ? 3 : 2, {dgamma, dbeta, dcolsum}}, s);
 }
 
 int hct_decoder_assemble_fwd(const void* e, int e_dtype, const float* mask_token, const float* dec_cls,

@@ -8,6 +8,7 @@
 // range and the ranges finish from the end of the buffer towards its start (gradient-bucket order for the
 // data-parallel all-reduce).  Names/shapes are the reference's; the Python side builds
 // nn.Parameter views by name, so state_dict order/keys are the reference's regardless of this layout.
+#include <cstdlib>
 #include "common.h"
 
 #include <map>
@@ -55,6 +56,7 @@ struct hct_mae_plan {
   std::vector<size_t> h_enc, h_dec;  // fp32 residual-stream chain
   std::vector<BlockA> aenc, adec;
   size_t s_dh, s_dh_shadow, s_dbig, s_dx, s_do, s_dqkv, s_small, s_small_bytes, s_gemm, s_gemm_bytes, s_nt_bytes = 0;
+  size_t s_fold_a = 0, s_fold_b = 0, s_fold_bytes = 0, s_small2 = 0, s_small2_bytes = 0;  // partial buffers of the deferred folds (block_backward)
   std::map<std::string, Act> acts;
   // bound buffers
   float* params_f32 = nullptr;
@@ -263,7 +265,7 @@ int linear_wgrad(hct_mae_plan* p, const void* dY, const void* X, int M, int N, i
   int rc = hct_gemm(&a, p->ws + p->s_gemm, p->s_gemm_bytes, s);
   p->gemm_ws_armed = rc == 0;
   if (rc) return rc;
-  if (b >= 0) rc = hct_colsum(dY, p->dt, M, N, N, p->gf(b), p->ws + p->s_small, p->s_small_bytes, s);
+  if (b >= 0) rc = hct_colsum(dY, p->dt, M, N, N, p->gf(b), p->ws + p->s_small2, p->s_small2_bytes, s);  // (s_small's head may hold a deferred fold's partials)
   return rc;
 }
 
@@ -305,6 +307,11 @@ int block_forward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const flo
 
 // in: dh (fp32 [M,d]) + shadow (compute dtype) = gradient wrt the block output.  out: same buffers hold the gradient
 // wrt the block input.  prev_fc2_b: bias index that receives colsum(d h_in) (the previous block's linear2 bias), or -1.
+bool defer_folds() {  // HCT_DEFER_FOLDS=0: every fold as a launch of its own (A/B runs)
+  static const bool on = [] { const char* v = getenv("HCT_DEFER_FOLDS"); return !(v && v[0] == '0'); }();
+  return on;
+}
+
 int block_backward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const float* h_in, int B, int N, int d, int m,
                    int heads, int prev_fc2_b, hipStream_t s) {
   const int M = B * N;
@@ -315,7 +322,15 @@ int block_backward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const fl
   void* dx = ws + p->s_dx;
   void* d_o = ws + p->s_do;
   void* dqkv = ws + p->s_dqkv;
-  void* small = ws + p->s_small;
+  // The three fixed-order folds of this block (fc1 bias column sums; ln2 and ln1 gamma / beta / column sums) are recorded and run as
+  // ONE launch at the end (common.h, FoldSink): each keeps a partial buffer of its own until then -- s_small's head, s_fold_a,
+  // s_fold_b -- and nothing else in between writes those.
+  FoldSink sink;
+  struct SinkScope {
+    FoldSink* prev;
+    explicit SinkScope(FoldSink* s_) : prev(g_fold_sink) { g_fold_sink = s_; }
+    ~SinkScope() { g_fold_sink = prev; }
+  } scope(defer_folds() ? &sink : g_fold_sink);
   // MLP branch
   RC(linear_wgrad(p, dhs, ws + ba.g, M, d, m, bp.fc2_w, -1, s));
   // d(pre-GELU) = (dh . W2) * gelu'(u); the linear1 bias gradient = column sums of this output rides in the same
@@ -325,8 +340,8 @@ int block_backward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const fl
   RC(linear_wgrad(p, dbig, ws + ba.x2, M, m, d, bp.fc1_w, -1, s));
   RC(linear_dgrad(p, dbig, M, m, bp.fc1_w, d, dx, HCT_ACT_NONE, nullptr, s));
   RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + ba.h_mid), (const float*)(ws + ba.mean2), (const float*)(ws + ba.rstd2),
-                       p->pf(bp.ln2_w), dh, M, d, dh, dhs, p->dt, p->gf(bp.ln2_w), p->gf(bp.ln2_b), p->gf(bp.proj_b), small,
-                       p->s_small_bytes, s));
+                       p->pf(bp.ln2_w), dh, M, d, dh, dhs, p->dt, p->gf(bp.ln2_w), p->gf(bp.ln2_b), p->gf(bp.proj_b), ws + p->s_fold_a,
+                       p->s_fold_bytes, s));
   // attention branch
   RC(linear_wgrad(p, dhs, ws + ba.o, M, d, d, bp.proj_w, -1, s));
   RC(linear_dgrad(p, dhs, M, d, bp.proj_w, d, d_o, HCT_ACT_NONE, nullptr, s));
@@ -334,9 +349,9 @@ int block_backward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const fl
   RC(linear_wgrad(p, dqkv, ws + ba.x1, M, 3 * d, d, bp.qkv_w, bp.qkv_b, s));
   RC(linear_dgrad(p, dqkv, M, 3 * d, bp.qkv_w, d, dx, HCT_ACT_NONE, nullptr, s));
   RC(hct_layernorm_bwd(dx, p->dt, h_in, (const float*)(ws + ba.mean1), (const float*)(ws + ba.rstd1), p->pf(bp.ln1_w), dh, M, d,
-                       dh, dhs, p->dt, p->gf(bp.ln1_w), p->gf(bp.ln1_b), prev_fc2_b >= 0 ? p->gf(prev_fc2_b) : nullptr, small,
-                       p->s_small_bytes, s));
-  return 0;
+                       dh, dhs, p->dt, p->gf(bp.ln1_w), p->gf(bp.ln1_b), prev_fc2_b >= 0 ? p->gf(prev_fc2_b) : nullptr, ws + p->s_fold_b,
+                       p->s_fold_bytes, s));
+  return fold_flush(sink, s);
 }
 
 }  // namespace
@@ -450,6 +465,11 @@ hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int comput
   small = std::max(small, hct_colsum_workspace_bytes((int)Md, p->pd));
   small = std::max(small, (size_t)((Mx + 255) / 256) * 4 * mlpx * sizeof(float));  // fused colsum partials of the dGELU dgrad
   small = align_up(small, 256);
+  p->s_fold_bytes = hct_layernorm_bwd_workspace_bytes((int)Mx, (int)Dx);
+  p->s_fold_a = w.take(p->s_fold_bytes);
+  p->s_fold_b = w.take(p->s_fold_bytes);
+  p->s_small2_bytes = small;  // (scratch of the wgrads' bias column sums: any of the sizes s_small was sized for)
+  p->s_small2 = w.take(p->s_small2_bytes);
   p->s_small_bytes = small;
   p->s_small = w.take(small);
   if (p->dt == HCT_BF16) {  // stream-K region of the persistent NT GEMM, directly behind s_small (see nt_gemm)
