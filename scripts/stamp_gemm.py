@@ -48,7 +48,7 @@ def call(name, M, N, K, out_f32=False, bias=False, residual=False, act=0, stagge
     us = e0.elapsed_time(e1) * 1e3
     s = stamps.cpu().numpy().astype(np.int64).reshape(256, 16, 4) & 0xFFFFFFFF
     tiles = (M // 256) * ((N + 255) // 256)
-    nblk = min(256, tiles)
+    nblk = 256 if os.environ.get('HCT_NT_STREAMK_PAIRS', '20') != '1000000' else min(256, tiles)
     s = s[:nblk]
     t0 = s[:, 0, 0].min()
     print(f"{name}: M={M} N={N} K={K} stagger={stagger}: {us:.1f} us, {2.0*M*N*K/us/1e6:.0f} TF, {tiles} tiles on {nblk} WGs")
@@ -73,3 +73,7 @@ for stg in ([int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()] or (-1, 0)
     if "fc1" in which: call("fc1 fwd (GELU, aux, bias)", Md, 3072, 768, bias=True, act=1, stagger=stg)
     if "dgelu" in which: call("fc2 dgrad (x gelu')", Md, 3072, 768, act=2, stagger=stg)
     if "proj" in which: call("proj fwd (+bias +res f32)", Md, 768, 768, out_f32=True, bias=True, residual=True, stagger=stg)
+    # 651 tiles: with the stream-K remainder round (default; HCT_NT_STREAMK_PAIRS=1000000 switches it off) item 0 / 1 of a
+    # workgroup are its follower / owner pieces, whose "epilogue issue" column is the slab hand-over / the fix-up + epilogue
+    if "fc1dgrad" in which: call("fc1 dgrad (plain bf16, K=3072)", Md, 768, 3072, stagger=stg)
+    if "encfc1dgrad" in which: call("encoder fc1 dgrad (plain bf16, K=3072, 165 tiles)", 256 * 55, 768, 3072, stagger=stg)
