@@ -45,7 +45,7 @@ VITL = dict(VITB, input_size=128, pos_embed="learnable", encoder_depth=24, encod
 WORKLOADS = {
     "vitb": (VITB, 256, "BASELINE config #2: MAE ViT-B/16^3, 96^3x1ch, mask 0.75, full train step (fwd+bwd+clip+AdamW+LR)",
              "CT-volumes/sec MAE pretrain step (96^3, ViT-B/16^3, mask 0.75)"),
-    "vitl": (VITL, 64, "BASELINE config #4: MAE ViT-L/16^3, 128^3x1ch, mask 0.75, decoder 768x8x16, full train step",
+    "vitl": (VITL, 96, "BASELINE config #4: MAE ViT-L/16^3, 128^3x1ch, mask 0.75, decoder 768x8x16, full train step",
              "CT-volumes/sec MAE pretrain step (128^3, ViT-L/16^3, mask 0.75)"),
 }
 
@@ -218,7 +218,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="vitb", choices=sorted(WORKLOADS) + ["dino"],
                     help="vitb = BASELINE config #2 (the headline metric), vitl = config #4, dino = config #5")
-    ap.add_argument("--batch", type=int, default=0, help="volumes per GPU (default: 256 for vitb, 64 for vitl, 8 for dino)")
+    ap.add_argument("--batch", type=int, default=0, help="volumes per GPU (default: 256 for vitb, 96 for vitl, 8 for dino)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket the dominant kernel with HIP events")
