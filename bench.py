@@ -89,7 +89,7 @@ def run_dino(args, world, rank, device):
     from headct_foundation_amd.dino import DINOLoss, DinoDataParallel, DinoOptimizer, update_momentum_encoder, wd_cosine_scheduler
     from headct_foundation_amd.dino_model import DINOHead, MultiCropWrapper, ViTBackbone
     from headct_foundation_amd.lr_sched import get_cosine_schedule_with_warmup
-    B, G, V = args.batch or 8, world, DINO["crops"]
+    B, G, V = args.batch or 64, world, DINO["crops"]  # the reference's DATA.BATCH_SIZE default (config.py:15)
     torch.manual_seed(42)
     mk = lambda: MultiCropWrapper(ViTBackbone(**DINO["vit"], compute_dtype=args.dtype), DINOHead(**DINO["head"], compute_dtype=args.dtype)).to(device)
     student, teacher = mk(), mk()
@@ -218,7 +218,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="vitb", choices=sorted(WORKLOADS) + ["dino"],
                     help="vitb = BASELINE config #2 (the headline metric), vitl = config #4, dino = config #5")
-    ap.add_argument("--batch", type=int, default=0, help="volumes per GPU (default: 256 for vitb, 96 for vitl, 8 for dino)")
+    ap.add_argument("--batch", type=int, default=0, help="volumes per GPU (default: 256 for vitb, 96 for vitl, 64 for dino)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket the dominant kernel with HIP events")
