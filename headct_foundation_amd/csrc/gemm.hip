@@ -969,6 +969,23 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
+  // Top of an item: pair (0,1) must have landed, pair (2,3) has just been issued.  Between the two this wave issued the previous
+  // item's epilogue -- a fixed number of vector-memory operations (loads and stores go out unconditionally, out-of-range lanes
+  // by descriptor) -- and operations retire in issue order, so allowing that many PLUS the 8 of pair (2,3) to be outstanding
+  // still means (0,1) is in LDS, while the previous tile's output stores keep draining under the first two K-steps instead of
+  // in front of them (2.2 us per tile by the in-kernel stamps).  An under-estimate is safe (it only waits longer).
+  // MEASURED: no change inside the step (39.83 / 39.91 with, 39.84 / 39.91 ms without, scripts/ab_step.py on one box) -- the drain
+  // moves to the full wait of the first odd K-step -- so the plain wait stays the default.
+#ifndef HCT_NT_COUNTED_TOP
+#define HCT_NT_COUNTED_TOP 0
+#endif
+  constexpr int kTopOps = 8 + EpiTraits<MODE>::ops_per_tile > 63 ? 63 : 8 + EpiTraits<MODE>::ops_per_tile;
+  auto land_top = [&](int younger) {  // younger: 0 = nothing issued since pair (0,1), 1 = a specialised epilogue, 2 = a follower's 32 slab stores
+    if (!HCT_NT_COUNTED_TOP || MODE == EPI_GENERIC || younger == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kTopOps) : "memory");
+    __builtin_amdgcn_s_barrier();
+  };
   // De-phase the persistent workgroups: all tiles cost the same, so without this every CU reaches its epilogue at the same
   // moment and the chip alternates between an HBM write burst (matrix pipes idle, vmcnt is in-order so the next tile
   // cannot start until the stores drain) and a pure-MFMA phase.  Eight start phases spread the bursts over the main loops
@@ -1055,6 +1072,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     stage_pair(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile: no epilogue behind the pairs to leave in flight
   }
+  int younger = 0;  // what this wave has issued since the current item's pair (0,1): see land_top
   while (true) {
     HCT_STAMP(0);
     const int cm0 = m0, cn0 = n0;  // item being computed (next_item below moves m0/n0 to the next one)
@@ -1074,7 +1092,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     } else {
       __builtin_amdgcn_s_barrier();
       stage_pair(2);
-      land_but_youngest_pair();
+      land_top(younger);
     }
     HCT_STAMP(1);
     rd_a(0, a0);
@@ -1156,7 +1174,9 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
       __syncthreads();
       if (threadIdx.x == 0)  // flag = launch sequence number | the XCD this workgroup really runs on
         __hip_atomic_store((unsigned*)sk_ws + blockIdx.x, (sk_seq << 4) | xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      younger = 0;  // (everything was drained for the flag)
     } else {
+      younger = 1;
       if (SK && ((item >> 28) & 7)) {
         // OWNER of a shared tile: add the followers' partials, workgroup order c+1, c+2, ...  Their bytes were stored
         // write-through and drained before the flag; the poll is relaxed, ONE agent-scope acquire then drops this CU's stale
