@@ -105,9 +105,10 @@ def _nt_call(lib, A, B, M, N, K, ws, out_dtype, bias=None, residual=None, act=0,
     return Cm
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 2048, 1024), (3000, 1008, 1536), (55552, 768, 3072), (55552, 3072, 768), (14080, 768, 2304),
-                                   (2000, 496, 512)])
-def test_gemm_nt_stream_k_remainder(lib, cuda, M, N, K):
+@pytest.mark.parametrize("M,N,K,reserve", [(2048, 2048, 1024, 0), (3000, 1008, 1536, 0), (55552, 768, 3072, 0), (55552, 3072, 768, 0),
+                                           (14080, 768, 2304, 0), (2000, 496, 512, 0), (55552, 768, 3072, 16), (3000, 1008, 1536, 16),
+                                           (14080, 768, 2304, 64)])
+def test_gemm_nt_stream_k_remainder(lib, cuda, M, N, K, reserve):
     """Persistent NT kernel with the remainder round shared out by K range: every epilogue instance against the whole-tile
     schedule (hook -1000-k: stream-K only for K >= k) and against fp32 torch, bit-identical repeats, flags consumed, no timeout.
     The shapes give 4 (first, last), 6 and ~26 / ~45 stage pairs per K range, ragged M and N, and the step's own worst cases
@@ -140,6 +141,7 @@ def test_gemm_nt_stream_k_remainder(lib, cuda, M, N, K):
 
     lib.hct_debug_set_gemm_variant(-1000 - 512)
     lib.hct_debug_set_gemm_variant(-100 - 1)  # take every remainder round that saves at least one pair
+    lib.hct_set_cu_reserve(reserve)  # the data-parallel wrapper leaves CUs to RCCL during the backward: grids of 240 / 192 workgroups
     try:
         flags.zero_()
         sk = run(0)
@@ -151,6 +153,7 @@ def test_gemm_nt_stream_k_remainder(lib, cuda, M, N, K):
     finally:
         lib.hct_debug_set_gemm_variant(-1000 - 512)
         lib.hct_debug_set_gemm_variant(-100 - 20)
+        lib.hct_set_cu_reserve(0)
     lib.hct_debug_set_gemm_variant(-1000 - (1 << 24))
     try:
         whole = run(0)
