@@ -127,6 +127,7 @@ _PROTOS = {
     "hct_mae_backward_stage_range": (c_int, [c_void_p, c_int, C.POINTER(c_int64), C.POINTER(c_int64)]),
     "hct_mae_backward_stage": (c_int, [c_void_p, c_int, c_void_p]),
     "hct_vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "hct_vit_forward_parts": (c_int, [c_void_p, C.POINTER(c_void_p), c_int, c_int, c_void_p]),
     "hct_vit_backward_stage": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "hct_vit_assemble_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hct_mae_plan_activation": (c_void_p, [c_void_p, C.c_char_p, C.POINTER(c_int64), C.POINTER(c_int64), C.POINTER(c_int)]),

@@ -607,15 +607,27 @@ int hct_mae_forward(hct_mae_plan* p, const void* x, int x_dtype, const float* no
 }
 
 int hct_vit_forward(hct_mae_plan* p, const void* x, int x_dtype, void* stream) {
-  HCT_REQUIRE(p && p->ws && x, "hct_vit_forward: plan not bound or null argument");
+  HCT_REQUIRE(x, "hct_vit_forward: null argument");
+  return hct_vit_forward_parts(p, &x, 1, x_dtype, stream);
+}
+
+int hct_vit_forward_parts(hct_mae_plan* p, const void* const* xs, int n_parts, int x_dtype, void* stream) {
+  HCT_REQUIRE(p && p->ws && xs && n_parts > 0, "hct_vit_forward: plan not bound or null argument");
   HCT_REQUIRE(p->vit, "hct_vit_forward: the plan was not created with encoder_only = 1");
   HCT_REQUIRE(x_dtype == HCT_F32 || x_dtype == HCT_F16, "hct_vit_forward: volumes are fp32 or fp16");
+  HCT_REQUIRE(p->B % n_parts == 0, "hct_vit_forward_parts: the plan's batch (%d) is not a multiple of the number of parts (%d)", p->B, n_parts);
   hipStream_t s = (hipStream_t)stream;
   unsigned char* ws = p->ws;
   const hct_mae_config& c = p->cfg;
-  const int B = p->B;
-  // PatchEmbeddingBlock on every patch (patch_embedding.py:149-156), class token and register tokens (vit.py:147-160)
-  RC(hct_patch_gather(x, x_dtype, nullptr, B, c.in_chans, c.input_size, c.patch_size, p->L, p->L, ws + p->a_patches, p->dt, s));
+  const int B = p->B, Bp = B / n_parts;
+  // PatchEmbeddingBlock on every patch (patch_embedding.py:149-156), class token and register tokens (vit.py:147-160).  The batch
+  // may arrive as several equally sized tensors (the crops MultiCropWrapper concatenates, misc.py:467-480): the patch rows are
+  // gathered straight from each of them, which is the concatenation without its copy.
+  for (int i = 0; i < n_parts; ++i) {
+    HCT_REQUIRE(xs[i], "hct_vit_forward_parts: null part %d", i);
+    RC(hct_patch_gather(xs[i], x_dtype, nullptr, Bp, c.in_chans, c.input_size, c.patch_size, p->L, p->L,
+                        ws + p->a_patches + (size_t)i * Bp * p->L * p->pd * p->esz(), p->dt, s));
+  }
   RC(linear_fwd(p, ws + p->a_patches, B * p->L, p->pd, p->p_pe_w, p->p_pe_b, p->D, ws + p->a_tok, p->dt, HCT_ACT_NONE, nullptr, nullptr, s));
   RC(hct_vit_assemble_fwd(ws + p->a_tok, p->dt, p->pf(p->p_cls), p->p_reg >= 0 ? p->pf(p->p_reg) : nullptr, p->p_pos >= 0 ? p->pf(p->p_pos) : nullptr, B,
                           p->L, p->R, p->D, (float*)(ws + p->h_enc[0]), s));

@@ -41,15 +41,17 @@ def _code(t: torch.Tensor) -> int:
 # ================================================================================================
 class _ViTFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, model, x, train):
-        plan = model._plan_for(x.shape[0])
+    def forward(ctx, anchor, model, train, *xs):
+        # xs: the batch as one tensor or as several equally shaped ones in batch order (crops that are not concatenated first)
+        B = sum(int(t.shape[0]) for t in xs)
+        plan = model._plan_for(B)
         st = _st()
         model._ensure_weights_fresh(plan, st)
-        xdt = _lib.HCT_F16 if x.dtype == torch.float16 else HCT_F32
-        _lib.check(plan.lib.hct_vit_forward(plan.handle, x.data_ptr(), xdt, st), "hct_vit_forward")
+        xdt = _lib.HCT_F16 if xs[0].dtype == torch.float16 else HCT_F32
+        ptrs = (C.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
+        _lib.check(plan.lib.hct_vit_forward_parts(plan.handle, ptrs, len(xs), xdt, st), "hct_vit_forward_parts")
         plan.serial += 1
-        ctx.model, ctx.plan, ctx.serial = model, plan, plan.serial
-        B = x.shape[0]
+        ctx.model, ctx.plan, ctx.serial, ctx.nx = model, plan, plan.serial, len(xs)
         lat = plan.activation("latent").view(B, model.num_tokens, model.hidden_size)
         return lat.clone()  # the workspace is reused by the next forward at this batch size
 
@@ -67,7 +69,7 @@ class _ViTFunction(torch.autograd.Function):
         model._keep_alive = d
         model._run_staged_backward(plan, lambda s: lib.hct_vit_backward_stage(plan.handle, s, d.data_ptr() if s == 0 else None, st),
                                    "hct_vit_backward_stage")
-        return None, None, None, None
+        return (None, None, None) + (None,) * ctx.nx
 
 
 class ViTBackbone(FlatPlanModule):
@@ -139,16 +141,22 @@ class ViTBackbone(FlatPlanModule):
                 nn.init.normal_(self.register_tokens, std=1e-6)
         self._build_flat(torch.device("cpu"))
 
-    def forward(self, x: torch.Tensor):
-        if not x.is_cuda:
-            raise HctError("ViTBackbone (HIP) got a CPU tensor: this path has no CPU fallback")
-        expect = (x.shape[0], self.in_chans, self.img_size, self.img_size, self.img_size)
-        if tuple(x.shape) != expect:
-            raise HctError(f"input shape {tuple(x.shape)} != {expect}")
-        x = x.contiguous() if x.dtype == torch.float16 else x.contiguous().float()
+    def forward(self, x):
+        """x: `[B, C, S, S, S]`, or a list / tuple of equally shaped tensors standing for their concatenation along the batch (the
+        crops of one resolution, which MultiCropWrapper would otherwise copy into one tensor first)."""
+        xs = list(x) if isinstance(x, (list, tuple)) else [x]
+        for t in xs:
+            if not t.is_cuda:
+                raise HctError("ViTBackbone (HIP) got a CPU tensor: this path has no CPU fallback")
+            expect = (t.shape[0], self.in_chans, self.img_size, self.img_size, self.img_size)
+            if tuple(t.shape) != expect:
+                raise HctError(f"input shape {tuple(t.shape)} != {expect}")
+        if any(t.shape[0] != xs[0].shape[0] or t.dtype != xs[0].dtype for t in xs):
+            xs = [torch.cat(xs)]  # unequal parts: the copy after all
+        xs = [t.contiguous() if t.dtype == torch.float16 else t.contiguous().float() for t in xs]
         if all(p.grad is None for p in self.parameters()):
             self._grad_overwrite = True
-        out = _ViTFunction.apply(self.cls_token, self, x, torch.is_grad_enabled())
+        out = _ViTFunction.apply(self.cls_token, self, torch.is_grad_enabled(), *xs)
         return out, []  # (normalised tokens, hidden_states_out): the per-block states are not materialised on this path
 
 
@@ -395,7 +403,7 @@ class MultiCropWrapper(nn.Module):
             end = start
             while end < len(x) and sizes[end] == sizes[start]:
                 end += 1
-            out = self.backbone(torch.cat(x[start:end]))
+            out = self.backbone(x[start:end] if hasattr(self.backbone, "_plan_for") else torch.cat(x[start:end]))  # the native backbone reads the crops in place
             feats.append(out[0] if isinstance(out, tuple) else out)
             start = end
         tokens = torch.cat(feats)

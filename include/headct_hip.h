@@ -370,6 +370,9 @@ int hct_mae_backward_stage(hct_mae_plan*, int stage, void* stream);
  * embedding); stage 0 takes dlatent [B*(1+R+L), D] in the compute dtype (the gradient w.r.t. "latent"; rows that do not
  * feed the loss are zero). */
 int hct_vit_forward(hct_mae_plan*, const void* x, int x_dtype, void* stream);
+/* The same forward with the batch given as `n_parts` tensors of batch / n_parts volumes each, in batch order: what
+ * MultiCropWrapper's torch.cat of equally sized crops (misc.py:467-480) would have produced, without the copy. */
+int hct_vit_forward_parts(hct_mae_plan*, const void* const* xs, int n_parts, int x_dtype, void* stream);
 int hct_vit_backward_stage(hct_mae_plan*, int stage, const void* dlatent, void* stream);
 int hct_vit_assemble_bwd(const float* dh0, int B, int L, int R, int D, void* dtok, int dtok_dtype, float* dcls, float* dreg, float* dpos,
                          void* stream);

@@ -92,6 +92,30 @@ def _build_pair(fx, dev, dtype, which):
     return MultiCropWrapper(b, h).to(dev), pb, ph
 
 
+@pytest.mark.gpu
+def test_backbone_reads_crops_in_place(lib, cuda):
+    """ViTBackbone on a list of equally shaped crops (hct_vit_forward_parts: patch rows gathered straight from each tensor) is
+    bit-identical, forward and backward, to the same backbone on their concatenation (MultiCropWrapper's torch.cat,
+    misc.py:467-480); unequal parts fall back to the copy."""
+    from headct_foundation_amd.dino_model import ViTBackbone
+    torch.manual_seed(3)
+    b = ViTBackbone(img_size=32, patch_size=16, in_chans=3, hidden_size=192, mlp_dim=384, num_layers=2, num_heads=3,
+                    num_register_tokens=2, compute_dtype="bf16").to(cuda)
+    crops = [torch.rand(2, 3, 32, 32, 32, device=cuda) for _ in range(3)]
+    outs, grads = [], []
+    for arg in (torch.cat(crops), crops, tuple(crops), [crops[0], torch.cat(crops[1:])]):
+        for p in b.parameters():
+            p.grad = None
+        out = b(arg)[0]
+        out.float().square().mean().backward()
+        torch.cuda.synchronize()
+        outs.append(out.detach().clone())
+        grads.append({n: p.grad.detach().clone() for n, p in b.named_parameters() if p.grad is not None})
+    for o, g in zip(outs[1:], grads[1:]):
+        assert torch.equal(o, outs[0])
+        assert g.keys() == grads[0].keys() and all(torch.equal(g[k], grads[0][k]) for k in g)
+
+
 @pytest.mark.parametrize("dtype,tol_loss,tol_grad", [("fp32", 2e-5, 1e-3), ("bf16", 2e-3, 5e-2)])
 def test_dino_step_vs_reference_fixture(lib, cuda, dtype, tol_loss, tol_grad):
     """One DINO iteration (engine_pretrain_dino.py:59-104: teacher on the two global crops, student on all crops through
