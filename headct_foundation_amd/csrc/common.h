@@ -80,6 +80,9 @@ template <typename T> struct Vec4;
 template <> struct Vec4<float> {
   static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
   static __device__ __forceinline__ void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+  // streamed once: non-temporal (does not displace what the neighbouring GEMMs re-read through L2)
+  static __device__ __forceinline__ f32x4 load_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+  static __device__ __forceinline__ void store_nt(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
 };
 template <> struct Vec4<bf16> {
   static __device__ __forceinline__ f32x4 load(const bf16* p) {
@@ -89,6 +92,10 @@ template <> struct Vec4<bf16> {
   static __device__ __forceinline__ void store(bf16* p, f32x4 v) {
     bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
     *reinterpret_cast<bf16x4*>(p) = o;
+  }
+  static __device__ __forceinline__ f32x4 load_nt(const bf16* p) {
+    bf16x4 v = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(p));
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
   }
 };
 

@@ -187,6 +187,11 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restr
   }
 }
 
+#ifdef HCT_LN_NT
+#define HCT_LN_NT_FWD HCT_LN_NT
+#else
+#define HCT_LN_NT_FWD 6  /* = the default of HCT_LN_NT below (bit 2: the forward's x load) */
+#endif
 // Register-resident variant (D <= 256 * NV): the row is loaded once (the kernel above reads it three times, one memory round
 // trip per pass), each wave walks rows w, w+W, ... with gamma / beta held in registers.  Same arithmetic in the same order.
 template <typename T, int NV>
@@ -211,7 +216,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd_reg_kernel(const float* __r
     for (int i = 0; i < NV; ++i) {
       const int d = lane * 4 + 256 * i;
       if (d < D) {
-        v[i] = Vec4<float>::load(xr + d);
+        v[i] = (HCT_LN_NT_FWD & 4) ? Vec4<float>::load_nt(xr + d) : Vec4<float>::load(xr + d);
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
       }
     }
@@ -252,6 +257,16 @@ __global__ void __launch_bounds__(256) layernorm_fwd_reg_kernel(const float* __r
 // =============================================================================================
 constexpr int kLnBwdBlocks = 1024;  // 4 workgroups = 16 waves per CU (36 KB of LDS each): the row loop is a load -> reduce -> store chain per wave
 
+// Cache policy of the LayerNorm kernels' streams (A/B builds: -DHCT_LN_NT=n): bit 0 = the backward's fp32 dx store non-temporal (it
+// is next read three GEMMs later), bit 1 = the backward's dy / x / residual-gradient loads non-temporal (last use), bit 2 = the
+// forward's x load non-temporal.
+// Measured inside the step (scripts/ab_step.py, variant libraries, two boxes): 4 -> -0.30 ms, 6 -> -0.44, 7 -> -0.45, 1 -> 0, 3 -> -0.1:
+// the forward's pass over the fp32 residual stream was evicting what the GEMMs around it re-read.
+#ifndef HCT_LN_NT
+#define HCT_LN_NT 6
+#endif
+template <typename T> __device__ __forceinline__ f32x4 ln_load_nt(const T* p) { return Vec4<T>::load_nt(p); }
+
 template <typename T, typename TS, int NV>
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -276,8 +291,8 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict_
     for (int i = 0; i < NV; ++i) {
       const int d = lane * 4 + 256 * i;
       if (d < D) {
-        dyv[i] = Vec4<T>::load(dy + (size_t)row * D + d);
-        xh[i] = (Vec4<float>::load(x + (size_t)row * D + d) - mu) * rs;
+        dyv[i] = (HCT_LN_NT & 2) ? ln_load_nt(dy + (size_t)row * D + d) : Vec4<T>::load(dy + (size_t)row * D + d);
+        xh[i] = (((HCT_LN_NT & 2) ? Vec4<float>::load_nt(x + (size_t)row * D + d) : Vec4<float>::load(x + (size_t)row * D + d)) - mu) * rs;
       } else {
         dyv[i] = xh[i] = f32x4{0, 0, 0, 0};
       }
@@ -295,8 +310,9 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict_
       const int d = lane * 4 + 256 * i;
       if (d < D) {
         f32x4 v = (dyv[i] * g[i] - s1 - xh[i] * s2) * rs;
-        if (dres) v += Vec4<float>::load(dres + (size_t)row * D + d);
-        Vec4<float>::store(dx + (size_t)row * D + d, v);
+        if (dres) v += (HCT_LN_NT & 2) ? Vec4<float>::load_nt(dres + (size_t)row * D + d) : Vec4<float>::load(dres + (size_t)row * D + d);
+        if (HCT_LN_NT & 1) Vec4<float>::store_nt(dx + (size_t)row * D + d, v);
+        else Vec4<float>::store(dx + (size_t)row * D + d, v);
         if (shadow) Vec4<TS>::store(shadow + (size_t)row * D + d, v);
         pc[i] += v;
       }
