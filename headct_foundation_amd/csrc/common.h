@@ -108,6 +108,10 @@ template <> struct Vec4<f16> {
     f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
     *reinterpret_cast<f16x4*>(p) = o;
   }
+  static __device__ __forceinline__ f32x4 load_nt(const f16* p) {
+    f16x4 v = __builtin_nontemporal_load(reinterpret_cast<const f16x4*>(p));
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
 };
 __device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
 

@@ -4,6 +4,11 @@
 // is needed (64 lanes x 4 elements = one 1 KiB fp32 request per step).
 #include "common.h"
 
+// A/B builds (-DHCT_MISC_NT=n): bit 0 = the loss kernel's volume / prediction loads non-temporal, bit 1 = the patch gather's volume loads
+#ifndef HCT_MISC_NT
+#define HCT_MISC_NT 0
+#endif
+
 #include <stdarg.h>
 #include <algorithm>
 
@@ -66,7 +71,7 @@ __global__ void patch_gather_kernel(const TX* __restrict__ x, const int32_t* __r
     const int ph = t % P; t /= P;
     const int c = t;
     const TX* src = x + ((((size_t)b * C + c) * S + (gh * P + ph)) * S + (gw * P + pw)) * S + gd * P + q * 4;
-    Vec4<T>::store(out + (size_t)v * 4, Vec4<TX>::load(src));
+    Vec4<T>::store(out + (size_t)v * 4, (HCT_MISC_NT & 2) ? Vec4<TX>::load_nt(src) : Vec4<TX>::load(src));
   }
 }
 
@@ -500,9 +505,10 @@ __global__ void __launch_bounds__(256) masked_mse_kernel(const T* __restrict__ p
       const int pz = u % P; u /= P;
       const int pw = u % P; u /= P;
       const int ph = u;
-      f32x4 tv = Vec4<TX>::load(vol + ((size_t)(gh * P + ph) * S + (gw * P + pw)) * S + gd * P + pz);
+      const TX* tp = vol + ((size_t)(gh * P + ph) * S + (gw * P + pw)) * S + gd * P + pz;
+      f32x4 tv = (HCT_MISC_NT & 1) ? Vec4<TX>::load_nt(tp) : Vec4<TX>::load(tp);
       tv = (tv - mu) * rsd;
-      const f32x4 df = Vec4<T>::load(prow + k) - tv;
+      const f32x4 df = ((HCT_MISC_NT & 1) ? Vec4<T>::load_nt(prow + k) : Vec4<T>::load(prow + k)) - tv;
       sse += (df[0] * df[0] + df[1] * df[1]) + (df[2] * df[2] + df[3] * df[3]);
       if (drow) Vec4<T>::store(drow + k, df * gscale);
     }
