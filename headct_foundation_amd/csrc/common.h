@@ -97,6 +97,10 @@ template <> struct Vec4<bf16> {
     bf16x4 v = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(p));
     return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
   }
+  static __device__ __forceinline__ void store_nt(bf16* p, f32x4 v) {
+    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(p));
+  }
 };
 
 template <> struct Vec4<f16> {

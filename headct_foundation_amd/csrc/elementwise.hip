@@ -247,7 +247,8 @@ __global__ void __launch_bounds__(256) layernorm_fwd_reg_kernel(const float* __r
       if (d < D) {
         f32x4 o = (v[i] - mu) * rs;
         o = o * g[i] + bt[i];
-        Vec4<T>::store(yr + d, o);
+        if (HCT_LN_NT_FWD & 8) Vec4<T>::store_nt(yr + d, o);
+        else Vec4<T>::store(yr + d, o);
       }
     }
   }
@@ -264,9 +265,10 @@ constexpr int kLnBwdBlocks = 1024;  // 4 workgroups = 16 waves per CU (36 KB of 
 
 // Cache policy of the LayerNorm kernels' streams (A/B builds: -DHCT_LN_NT=n): bit 0 = the backward's fp32 dx store non-temporal (it
 // is next read three GEMMs later), bit 1 = the backward's dy / x / residual-gradient loads non-temporal (last use), bit 2 = the
-// forward's x load non-temporal.
+// forward's x load non-temporal, bit 3 = the forward's y store, bit 4 = the backward's shadow (GEMM operand) store.
 // Measured inside the step (scripts/ab_step.py, variant libraries, two boxes): 4 -> -0.30 ms, 6 -> -0.44, 7 -> -0.45, 1 -> 0, 3 -> -0.1:
-// the forward's pass over the fp32 residual stream was evicting what the GEMMs around it re-read.
+// the forward's pass over the fp32 residual stream was evicting what the GEMMs around it re-read.  The OUTPUTS the next GEMM reads must
+// stay cacheable: 6 + 8 (forward's y store non-temporal) -> +0.5 ms, 6 + 16 (backward's shadow store) -> +0.2 ms.
 #ifndef HCT_LN_NT
 #define HCT_LN_NT 6
 #endif
@@ -318,7 +320,10 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict_
         if (dres) v += (HCT_LN_NT & 2) ? Vec4<float>::load_nt(dres + (size_t)row * D + d) : Vec4<float>::load(dres + (size_t)row * D + d);
         if (HCT_LN_NT & 1) Vec4<float>::store_nt(dx + (size_t)row * D + d, v);
         else Vec4<float>::store(dx + (size_t)row * D + d, v);
-        if (shadow) Vec4<TS>::store(shadow + (size_t)row * D + d, v);
+        if (shadow) {
+          if (HCT_LN_NT & 16) Vec4<TS>::store_nt(shadow + (size_t)row * D + d, v);
+          else Vec4<TS>::store(shadow + (size_t)row * D + d, v);
+        }
         pc[i] += v;
       }
     }
