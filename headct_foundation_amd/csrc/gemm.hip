@@ -488,7 +488,7 @@ constexpr int kNT = HCT_EPI_CACHE_POLICY;
 #define HCT_BF16_OUT_POLICY HCT_EPI_CACHE_POLICY  /* bf16 outputs (qkv, GELU(u), dgrads): nt 40.15 ms per step, sc1 40.93, write-back 41.15 */
 #endif
 #ifndef HCT_RES_POLICY
-#define HCT_RES_POLICY 16  /* the fp32 residual-stream output, read back by the next LayerNorm: sc1 39.76 / write-back 39.77 / nt 39.84 ms per step */
+#define HCT_RES_POLICY 16  /* the fp32 residual-stream output, read back by the next LayerNorm: sc1 39.76 / write-back 39.77 / nt 39.84 ms per step; with LayerNorm's non-temporal loads: sc1 39.28 / write-back 39.33 / nt 39.45 */
 #endif
 #ifndef HCT_SLAB_POLICY
 #define HCT_SLAB_POLICY 16  /* cache policy of the wgrad's split-K slab stores: 16 = sc1 write-through (39.83 ms per step), 0 = write-back (39.90), 2 = nt (40.17) */
