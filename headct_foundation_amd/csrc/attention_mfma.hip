@@ -949,6 +949,9 @@ __device__ __forceinline__ attn_i32x4 attn_srd(const void* base, int64_t bytes) 
   return attn_i32x4{(int)__builtin_amdgcn_readfirstlane((uint32_t)pa), (int)(__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) & 0xFFFF),
                     (int)__builtin_amdgcn_readfirstlane(rec), 0x00020000};
 }
+#ifndef HCT_ATTN_OUT_NT  // measured: +0.6 ms per step (the wgrad / dgrad GEMMs that read dqkv next want it cacheable)
+#define HCT_ATTN_OUT_NT 0
+#endif
 #ifndef HCT_ATTN_DMA_NT  // A/B builds: 1 = the persistent kernels' Q / K / V / dO image loads non-temporal (read once per launch); measured: within noise (-0.08 ms)
 #define HCT_ATTN_DMA_NT 0
 #endif
@@ -1208,7 +1211,11 @@ __global__ void __launch_bounds__(1024 / KT, 2 * 2 / KT) attn_bwd4_kernel(const 
       const int q = qbk * 32 + 16 * hh + (ln & 15);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
+#if HCT_ATTN_OUT_NT
+        if (q < N) Vec4<bf16>::store_nt(dqkv + ((int64_t)b * N + q) * rs + h * DH + (dt0 + j) * 16 + 4 * g, dq[j]);
+#else
         if (q < N) Vec4<bf16>::store(dqkv + ((int64_t)b * N + q) * rs + h * DH + (dt0 + j) * 16 + 4 * g, dq[j]);
+#endif
     };
     auto dq_part = [&](int qbk, int ln) {
       if (dq_n == 1) dq_tiles(qbk, dq_hh, dq_dt0, std::integral_constant<int, 1>{}, ln);
@@ -1242,8 +1249,13 @@ __global__ void __launch_bounds__(1024 / KT, 2 * 2 / KT) attn_bwd4_kernel(const 
           bf16* outv = outk + H * DH;
 #pragma unroll
           for (int dt = 0; dt < ND; ++dt) {
+#if HCT_ATTN_OUT_NT  // A/B builds: the persistent backward's dQ / dK / dV stores non-temporal (the GEMM epilogues' bf16 outputs do best that way)
+            Vec4<bf16>::store_nt(outk + dt * 16, dKt[t][dt]);
+            Vec4<bf16>::store_nt(outv + dt * 16, dVt[t][dt]);
+#else
             Vec4<bf16>::store(outk + dt * 16, dKt[t][dt]);
             Vec4<bf16>::store(outv + dt * 16, dVt[t][dt]);
+#endif
           }
         }
       }
