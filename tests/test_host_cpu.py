@@ -30,6 +30,36 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.hct_version() >= 100 and lib.hct_has_mfma_kernels() == 1
 
 
+def test_gemm_workspace_sizes_host_side(lib):
+    """hct_gemm_workspace_bytes / hct_gemm_nt_flags_offset are host arithmetic (no device call): a forward / dgrad product of
+    K >= 512 asks for the stream-K region (64 MiB of slabs + a 4 KiB head) behind its column-sum partials, shorter K does not,
+    and the flags sit at a 256-byte aligned offset from the END of whatever workspace is passed."""
+    from headct_foundation_amd._lib import HCT_BF16, GemmArgs
+    sk = 256 * 262144 + 4096
+
+    def nt(M, N, K, colsum=False):
+        a = GemmArgs()
+        a.M, a.N, a.K = M, N, K
+        a.A, a.a_dtype, a.lda, a.transA = 256, HCT_BF16, K, 0  # (alignment probes: nothing is dereferenced)
+        a.B, a.b_dtype, a.ldb, a.transB = 256, HCT_BF16, K, 1
+        a.C, a.c_dtype, a.ldc = 256, HCT_BF16, N
+        a.alpha = 1.0
+        if colsum:
+            a.colsum_out = 256
+        return lib.hct_gemm_workspace_bytes(C.byref(a))
+
+    assert nt(55552, 768, 3072) == sk and nt(1000, 768, 512) == sk
+    assert nt(55552, 3072, 256) == 0 and nt(55552, 768, 448) == 0  # K < 512, or not a multiple of 64 on the persistent kernel
+    with_cs = nt(55552, 3072, 768, colsum=True)
+    assert with_cs > sk and (with_cs - sk) % 256 == 0 and with_cs - sk >= 217 * 4 * 3072 * 4
+    none = 2 ** 64 - 1
+    assert lib.hct_gemm_nt_flags_offset(0) == none and lib.hct_gemm_nt_flags_offset(sk - 1) == none
+    assert lib.hct_gemm_nt_flags_offset(sk) == 0
+    for extra in (1, 255, 256, 1000, 12345678):
+        off = lib.hct_gemm_nt_flags_offset(sk + extra)
+        assert off % 256 == 0 and off <= extra and extra - off < 256
+
+
 @pytest.mark.parametrize("name", ["micro", "yaml_cut", "tiny", "vitb_cut"])
 def test_module_mirrors_reference_state_dict(lib, name):
     """Keys, order, shapes and dtypes of state_dict() equal the manifest dumped from the reference model."""
