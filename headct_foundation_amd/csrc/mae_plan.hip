@@ -219,7 +219,10 @@ hct_gemm_args base_args() {
 int nt_gemm(hct_mae_plan* p, hct_gemm_args& a, hipStream_t s) {
   if (p->s_nt_bytes == 0) return hct_gemm(&a, a.colsum_out ? p->ws + p->s_small : nullptr, a.colsum_out ? p->s_small_bytes : 0, s);
   if (!p->nt_ws_armed) {
-    if (hipMemsetAsync(p->ws + p->s_small + p->s_small_bytes, 0, p->s_nt_bytes, s) != hipSuccess) return HCT_E_WORKSPACE;
+    if (hipMemsetAsync(p->ws + p->s_small + p->s_small_bytes, 0, p->s_nt_bytes, s) != hipSuccess) {
+      set_error("plan: clearing the stream-K region of the GEMM workspace failed");
+      return HCT_E_WORKSPACE;
+    }
     p->nt_ws_armed = true;
   }
   a.workspace_armed = 1;
