@@ -32,6 +32,21 @@ class GemmArgs(C.Structure):
     ]
 
 
+class ProfShape(C.Structure):
+    """include/headct_hip.h hct_prof_shape: launches of one GEMM shape recorded by the in-library HIP-event profile"""
+    _fields_ = [("M", c_int), ("N", c_int), ("K", c_int), ("mode", c_int), ("tiles", c_int), ("sk_tiles", c_int),
+                ("launches", c_int64), ("total_ms", C.c_double), ("work", C.c_double), ("bytes", C.c_double)]
+
+
+def prof_shapes(lib, kernel_class: int, cap: int = 256):
+    """List of ProfShape entries of the recorded launches of a kernel class (0 = NT GEMM, 1 = wgrad GEMM)."""
+    buf = (ProfShape * cap)()
+    n = lib.hct_prof_shapes(kernel_class, C.cast(buf, c_void_p), cap)
+    if n < 0:
+        raise HctError("hct_prof_shapes failed")
+    return [buf[i] for i in range(min(n, cap))]
+
+
 class MaeConfig(C.Structure):
     _fields_ = [
         ("input_size", c_int), ("patch_size", c_int), ("in_chans", c_int), ("mask_ratio", C.c_double),
@@ -68,6 +83,10 @@ _PROTOS = {
     "hct_layernorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "hct_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hct_layernorm_bwd_mapped": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                         c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hct_tail_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "hct_gather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "hct_attention_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "hct_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "hct_debug_force_simple_attention": (None, [c_int]),
@@ -107,10 +126,14 @@ _PROTOS = {
                                c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "hct_debug_set_gemm_variant": (None, [c_int]),
     "hct_debug_set_gemm_stagger": (None, [c_int]),
+    "hct_gemm_tn_group_workspace_bytes": (c_size_t, [c_int]),
+    "hct_gemm_tn_group_prepare": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "hct_gemm_tn_group_run": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "hct_prof_enable": (None, [c_int]),
     "hct_prof_reset": (None, []),
     "hct_prof_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double)]),
     "hct_prof_read_bytes": (c_int, [c_int, C.POINTER(C.c_double)]),
+    "hct_prof_shapes": (c_int, [c_int, c_void_p, c_int]),
     "hct_mae_plan_create": (c_void_p, [C.POINTER(MaeConfig), c_int, c_int]),
     "hct_mae_plan_destroy": (None, [c_void_p]),
     "hct_mae_plan_num_params": (c_int, [c_void_p]),
@@ -119,6 +142,7 @@ _PROTOS = {
     "hct_mae_plan_bf16_t_elems": (c_int64, [c_void_p]),
     "hct_mae_plan_workspace_bytes": (c_size_t, [c_void_p]),
     "hct_mae_plan_len_keep": (c_int, [c_void_p]),
+    "hct_mae_plan_set_tail": (c_int, [c_void_p, c_int]),
     "hct_mae_plan_bind": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "hct_mae_refresh_weights": (c_int, [c_void_p, c_int, c_void_p]),
     "hct_mae_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p]),

@@ -278,6 +278,7 @@ template <typename T, typename TS, int NV>
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* dres,
+                                                            const int32_t* __restrict__ dres_rows,
                                                             int rows, int D, float* dx, TS* __restrict__ shadow,
                                                             float* __restrict__ partial, int want_colsum) {
   __shared__ float s_red[4][3][NV * 256];
@@ -292,6 +293,9 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict_
   }
   for (int row = wid; row < rows; row += nw) {
     const float mu = mean[row], rs = rstd[row];
+    // residual gradient of this row: row `row` of dres, or -- with a row map (the compact tail of the MAE decoder) -- row
+    // dres_rows[row] of a compact matrix, nothing where the map says -1
+    const int rrow = dres_rows ? dres_rows[row] : row;
     f32x4 dyv[NV], xh[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -317,7 +321,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict_
       const int d = lane * 4 + 256 * i;
       if (d < D) {
         f32x4 v = (dyv[i] * g[i] - s1 - xh[i] * s2) * rs;
-        if (dres) v += (HCT_LN_NT & 2) ? Vec4<float>::load_nt(dres + (size_t)row * D + d) : Vec4<float>::load(dres + (size_t)row * D + d);
+        if (dres && rrow >= 0) v += (HCT_LN_NT & 2) ? Vec4<float>::load_nt(dres + (size_t)rrow * D + d) : Vec4<float>::load(dres + (size_t)rrow * D + d);
         if (HCT_LN_NT & 1) Vec4<float>::store_nt(dx + (size_t)row * D + d, v);
         else Vec4<float>::store(dx + (size_t)row * D + d, v);
         if (shadow) {
@@ -458,25 +462,39 @@ template <typename TX, typename T>
 __global__ void __launch_bounds__(256) masked_mse_kernel(const T* __restrict__ pred, const TX* __restrict__ x,
                                                          const float* __restrict__ mask, int C, int S, int P, int L,
                                                          int norm_pix, float inv_masksum, float* __restrict__ row_loss,
-                                                         T* __restrict__ dpred, const float* __restrict__ dscale, float hscale) {
+                                                         T* __restrict__ dpred, const float* __restrict__ dscale, float hscale,
+                                                         const int32_t* __restrict__ masked_ids, int K) {
   __shared__ float s_tmp[4];
   const int r = blockIdx.x;
-  const int b = r / (L + 1), t = r - b * (L + 1);
   const int pd = P * P * P * C;
   const T* prow = pred + (size_t)r * pd;
   T* drow = dpred ? dpred + (size_t)r * pd : nullptr;
-  if (t == 0) {
-    if (drow)
-      for (int k = threadIdx.x * 4; k < pd; k += 1024) Vec4<T>::store(drow + k, f32x4{0, 0, 0, 0});
-    return;
-  }
-  const int l = t - 1;
-  const float m = mask[(size_t)b * L + l];
-  if (m == 0.f) {  // kept token: contributes nothing (mask = 0) and has zero gradient
-    if (threadIdx.x == 0 && row_loss) row_loss[(size_t)b * L + l] = 0.f;
-    if (drow)
-      for (int k = threadIdx.x * 4; k < pd; k += 1024) Vec4<T>::store(drow + k, f32x4{0, 0, 0, 0});
-    return;
+  int b, l;
+  size_t lrow;  // slot of this row's loss
+  if (masked_ids) {
+    // compact form: pred / dpred hold ONLY the masked patches' rows, row r = (volume b, j-th masked patch in shuffle order),
+    // masked_ids = ids_shuffle (mae.py:209: its entries K.. are the removed patches); the loss never sees another row (mae.py:298-299)
+    const int Lm = L - K;
+    b = r / Lm;
+    l = masked_ids[(size_t)b * L + K + (r - b * Lm)];
+    lrow = r;
+  } else {
+    b = r / (L + 1);
+    const int t = r - b * (L + 1);
+    if (t == 0) {
+      if (drow)
+        for (int k = threadIdx.x * 4; k < pd; k += 1024) Vec4<T>::store(drow + k, f32x4{0, 0, 0, 0});
+      return;
+    }
+    l = t - 1;
+    lrow = (size_t)b * L + l;
+    const float m = mask[lrow];
+    if (m == 0.f) {  // kept token: contributes nothing (mask = 0) and has zero gradient
+      if (threadIdx.x == 0 && row_loss) row_loss[lrow] = 0.f;
+      if (drow)
+        for (int k = threadIdx.x * 4; k < pd; k += 1024) Vec4<T>::store(drow + k, f32x4{0, 0, 0, 0});
+      return;
+    }
   }
   const int g = S / P;
   const int gh = l / (g * g), gw = (l / g) % g, gd = l % g;
@@ -525,7 +543,7 @@ __global__ void __launch_bounds__(256) masked_mse_kernel(const T* __restrict__ p
     }
   }
   sse = block_sum_256(sse, s_tmp);
-  if (threadIdx.x == 0 && row_loss) row_loss[(size_t)b * L + l] = sse / (float)pd;
+  if (threadIdx.x == 0 && row_loss) row_loss[lrow] = sse / (float)pd;
 }
 
 __global__ void __launch_bounds__(256) loss_fold_kernel(const float* __restrict__ row_loss, int n, float inv_masksum,
@@ -758,11 +776,11 @@ using namespace hct;
 
 template <typename T, typename TS>
 static int launch_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                         const float* dres, int rows, int D, float* dx, void* shadow, float* partial, int want_colsum,
-                         int nblk, hipStream_t s) {
+                         const float* dres, const int32_t* dres_rows, int rows, int D, float* dx, void* shadow, float* partial,
+                         int want_colsum, int nblk, hipStream_t s) {
 #define HCT_LN_CASE(NV)                                                                                               \
   hipLaunchKernelGGL((layernorm_bwd_kernel<T, TS, NV>), dim3(nblk), dim3(256), 0, s, (const T*)dy, x, mean, rstd, gamma, \
-                     dres, rows, D, dx, (TS*)shadow, partial, want_colsum)
+                     dres, dres_rows, rows, D, dx, (TS*)shadow, partial, want_colsum)
   const int nv = (D + 255) / 256;
   switch (nv) {
     case 1: HCT_LN_CASE(1); break;
@@ -904,6 +922,34 @@ __global__ void __launch_bounds__(256) scale_unless_one_kernel(T* __restrict__ b
 }
 
 namespace hct {
+__global__ void __launch_bounds__(256) tail_rows_kernel(const int32_t* __restrict__ ids_restore, int B, int L, int K,
+                                                        int32_t* __restrict__ tail_rows, int32_t* __restrict__ tail_inv) {
+  const int r = blockIdx.x * 256 + threadIdx.x;  // decoder row b * (L + 1) + t
+  if (r >= B * (L + 1)) return;
+  const int b = r / (L + 1), t = r - b * (L + 1);
+  int c = -1;
+  if (t > 0) {
+    const int rank = ids_restore[(size_t)b * L + (t - 1)];  // position of patch t-1 in the shuffle (mae.py:210)
+    if (rank >= K) {
+      c = b * (L - K) + (rank - K);
+      tail_rows[c] = r;
+    }
+  }
+  tail_inv[r] = c;
+}
+
+__global__ void __launch_bounds__(256) gather_rows16_kernel(const uint4* __restrict__ src, const int32_t* __restrict__ idx, int n_rows,
+                                                            int chunks, uint4* __restrict__ dst) {
+  const int64_t total = (int64_t)n_rows * chunks;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / chunks), c = (int)(i - (int64_t)r * chunks);
+    const int sr = idx[r];
+    uint4 v = {0u, 0u, 0u, 0u};
+    if (sr >= 0) v = src[(size_t)sr * chunks + c];
+    dst[i] = v;
+  }
+}
+
 int scale_unless_one(void* buf, int dtype, int64_t n, const float* scale, hipStream_t s) {
   HCT_REQUIRE(n % 4 == 0 && scale, "scale_unless_one: n %% 4 != 0 or null scale");
   const int blocks = (int)std::min<int64_t>(2048, (n / 4 + 255) / 256);
@@ -915,22 +961,24 @@ int scale_unless_one(void* buf, int dtype, int64_t n, const float* scale, hipStr
 
 int masked_mse_launch(const void* pred, int pred_dtype, const void* x, int x_dtype, const float* mask, int B, int C, int S, int P,
                       int norm_pix, float mask_sum, float* row_loss, float* loss, void* dpred, const float* dpred_scale,
-                      float host_scale, hipStream_t s) {
+                      float host_scale, hipStream_t s, const int32_t* masked_ids, int K) {
   HCT_REQUIRE(P % 4 == 0 && S % P == 0 && mask_sum > 0.f, "hct_masked_mse: bad geometry S=%d P=%d mask_sum=%f", S, P, mask_sum);
   HCT_REQUIRE(x_dtype == HCT_F32 || x_dtype == HCT_F16, "hct_masked_mse: volumes are fp32 or fp16");
   const int g = S / P, L = g * g * g;
   const int pd = P * P * P * C;
   HCT_REQUIRE(pd % 4 == 0, "hct_masked_mse: patch dim %% 4 != 0");
   const float inv = 1.0f / mask_sum;
+  HCT_REQUIRE(!masked_ids || (K >= 0 && K < L), "hct_masked_mse: compact form needs 0 <= K < L");
+  const int nrows = masked_ids ? B * (L - K) : B * (L + 1);  // prediction rows visited = blocks
   if (x_dtype == HCT_F16) {
     HCT_DISPATCH_DTYPE(pred_dtype, T,
-                       hipLaunchKernelGGL((masked_mse_kernel<f16, T>), dim3(B * (L + 1)), dim3(256), 0, s, (const T*)pred, (const f16*)x, mask,
-                                          C, S, P, L, norm_pix, inv, loss ? row_loss : nullptr, (T*)dpred, dpred_scale, host_scale));
+                       hipLaunchKernelGGL((masked_mse_kernel<f16, T>), dim3(nrows), dim3(256), 0, s, (const T*)pred, (const f16*)x, mask,
+                                          C, S, P, L, norm_pix, inv, loss ? row_loss : nullptr, (T*)dpred, dpred_scale, host_scale, masked_ids, K));
   } else
   HCT_DISPATCH_DTYPE(pred_dtype, T,
-                     hipLaunchKernelGGL((masked_mse_kernel<float, T>), dim3(B * (L + 1)), dim3(256), 0, s, (const T*)pred, (const float*)x, mask,
-                                        C, S, P, L, norm_pix, inv, loss ? row_loss : nullptr, (T*)dpred, dpred_scale, host_scale));
-  if (loss) hipLaunchKernelGGL(loss_fold_kernel, dim3(1), dim3(256), 0, s, row_loss, B * L, inv, loss);
+                     hipLaunchKernelGGL((masked_mse_kernel<float, T>), dim3(nrows), dim3(256), 0, s, (const T*)pred, (const float*)x, mask,
+                                        C, S, P, L, norm_pix, inv, loss ? row_loss : nullptr, (T*)dpred, dpred_scale, host_scale, masked_ids, K));
+  if (loss) hipLaunchKernelGGL(loss_fold_kernel, dim3(1), dim3(256), 0, s, row_loss, masked_ids ? B * (L - K) : B * L, inv, loss);
   HCT_CHECK_LAUNCH("hct_masked_mse");
   return 0;
 }
@@ -1048,7 +1096,16 @@ int hct_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
                       const float* gamma, const float* dres, int rows, int D, float* dx, void* dx_shadow,
                       int shadow_dtype, float* dgamma, float* dbeta, float* dcolsum, void* workspace,
                       size_t workspace_bytes, void* stream) {
+  return hct_layernorm_bwd_mapped(dy, dy_dtype, x, mean, rstd, gamma, dres, nullptr, rows, D, dx, dx_shadow, shadow_dtype, dgamma, dbeta,
+                                  dcolsum, workspace, workspace_bytes, stream);
+}
+
+int hct_layernorm_bwd_mapped(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
+                             const float* gamma, const float* dres, const int32_t* dres_rows, int rows, int D, float* dx,
+                             void* dx_shadow, int shadow_dtype, float* dgamma, float* dbeta, float* dcolsum, void* workspace,
+                             size_t workspace_bytes, void* stream) {
   HCT_REQUIRE(D % 4 == 0 && rows > 0, "hct_layernorm_bwd: bad shape rows=%d D=%d", rows, D);
+  HCT_REQUIRE(!dres_rows || (dres && (const void*)dres != (const void*)dx), "hct_layernorm_bwd_mapped: a mapped residual gradient cannot alias dx");
   if (workspace_bytes < hct_layernorm_bwd_workspace_bytes(rows, D)) {
     set_error("hct_layernorm_bwd: workspace too small");
     return HCT_E_WORKSPACE;
@@ -1058,11 +1115,11 @@ int hct_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
   float* partial = (float*)workspace;
   int rc = 0;
   if (dy_dtype == HCT_BF16) {
-    if (dx_shadow && shadow_dtype == HCT_F32) rc = launch_ln_bwd<bf16, float>(dy, x, mean, rstd, gamma, dres, rows, D, dx, dx_shadow, partial, dcolsum != nullptr, nblk, s);
-    else rc = launch_ln_bwd<bf16, bf16>(dy, x, mean, rstd, gamma, dres, rows, D, dx, dx_shadow, partial, dcolsum != nullptr, nblk, s);
+    if (dx_shadow && shadow_dtype == HCT_F32) rc = launch_ln_bwd<bf16, float>(dy, x, mean, rstd, gamma, dres, dres_rows, rows, D, dx, dx_shadow, partial, dcolsum != nullptr, nblk, s);
+    else rc = launch_ln_bwd<bf16, bf16>(dy, x, mean, rstd, gamma, dres, dres_rows, rows, D, dx, dx_shadow, partial, dcolsum != nullptr, nblk, s);
   } else {
-    if (dx_shadow && shadow_dtype == HCT_BF16) rc = launch_ln_bwd<float, bf16>(dy, x, mean, rstd, gamma, dres, rows, D, dx, dx_shadow, partial, dcolsum != nullptr, nblk, s);
-    else rc = launch_ln_bwd<float, float>(dy, x, mean, rstd, gamma, dres, rows, D, dx, dx_shadow, partial, dcolsum != nullptr, nblk, s);
+    if (dx_shadow && shadow_dtype == HCT_BF16) rc = launch_ln_bwd<float, bf16>(dy, x, mean, rstd, gamma, dres, dres_rows, rows, D, dx, dx_shadow, partial, dcolsum != nullptr, nblk, s);
+    else rc = launch_ln_bwd<float, float>(dy, x, mean, rstd, gamma, dres, dres_rows, rows, D, dx, dx_shadow, partial, dcolsum != nullptr, nblk, s);
   }
   if (rc) return rc;
   HCT_CHECK_LAUNCH("hct_layernorm_bwd");
@@ -1109,7 +1166,31 @@ int hct_masked_mse(const void* pred, int pred_dtype, const void* x, int x_dtype,
                    int norm_pix, float mask_sum, float* row_loss, float* loss, void* dpred, const float* dpred_scale,
                    void* stream) {
   return masked_mse_launch(pred, pred_dtype, x, x_dtype, mask, B, C, S, P, norm_pix, mask_sum, row_loss, loss, dpred, dpred_scale, 1.0f,
-                           (hipStream_t)stream);
+                           (hipStream_t)stream, nullptr, 0);
+}
+
+// Rows the loss sees (mae.py:298-299 keeps only the removed patches): for every volume the decoder rows of its L - K masked
+// patches, in shuffle order.  tail_rows[b * (L-K) + j] = row of the [B, L+1] decoder layout; tail_inv = the inverse, -1 for
+// the class token and the kept patches.
+int hct_tail_rows(const int32_t* ids_restore, int B, int L, int K, int32_t* tail_rows, int32_t* tail_inv, void* stream) {
+  HCT_REQUIRE(ids_restore && tail_rows && tail_inv && B > 0 && L > 0 && K >= 0 && K < L, "hct_tail_rows: bad arguments");
+  const int n = B * (L + 1);
+  hipLaunchKernelGGL(hct::tail_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ids_restore, B, L, K, tail_rows, tail_inv);
+  HCT_CHECK_LAUNCH("hct_tail_rows");
+  return 0;
+}
+
+// dst row r = src row idx[r] (any order, repeats allowed), zeros where idx[r] < 0.  Rows are row_bytes long (a multiple of 16,
+// both bases 16-byte aligned): the gather of the decoder's masked rows and, with the inverse map, the scatter back.
+int hct_gather_rows(const void* src, const int32_t* idx, int n_rows, int row_bytes, void* dst, void* stream) {
+  HCT_REQUIRE(src && idx && dst && n_rows >= 0 && row_bytes > 0 && row_bytes % 16 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
+              "hct_gather_rows: bad arguments (rows of a multiple of 16 bytes, 16-byte aligned)");
+  if (n_rows == 0) return 0;
+  const int64_t total = (int64_t)n_rows * (row_bytes / 16);
+  const int blocks = (int)std::min<int64_t>(8192, (total + 255) / 256);
+  hipLaunchKernelGGL(hct::gather_rows16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, idx, n_rows, row_bytes / 16, (uint4*)dst);
+  HCT_CHECK_LAUNCH("hct_gather_rows");
+  return 0;
 }
 
 int hct_unpatchify(const void* pred, int pred_dtype, int has_cls_row, int B, int C, int S, int P, float* vol,

@@ -53,6 +53,15 @@ struct hct_mae_plan {
   size_t ws_bytes = 0;
   size_t a_ids_restore, a_ids_shuffle, a_mask, a_row_loss, a_patches, a_tok, a_latent, a_lat_mean, a_lat_rstd, a_e,
       a_ynorm, a_yn_mean, a_yn_rstd, a_pred, a_dpred;
+  // Compact tail of the decoder (hct_mae_plan_set_tail): the loss takes only the masked patches' rows (mae.py:298-299), so
+  // everything behind the LAST decoder block's attention -- its proj / MLP, decoder_norm, decoder_pred, the loss and their
+  // backward -- runs on those Mc = B * (L - K) rows alone (75 % of the rows at mask_ratio 0.75), gathered into compact
+  // matrices; the block's LN1 / qkv / attention keep every row (keys and values of all tokens are needed).
+  bool tail = false;      // mode of the next forward
+  bool tail_fwd = false;  // mode the last forward ran in (its backward follows it)
+  bool tail_ok = false;   // the geometry allows it
+  int Mc = 0;
+  size_t a_tail_rows = 0, a_tail_inv = 0, a_oc = 0, s_dhc = 0;
   std::vector<size_t> h_enc, h_dec;  // fp32 residual-stream chain
   std::vector<BlockA> aenc, adec;
   size_t s_dh, s_dh_shadow, s_dbig, s_dx, s_do, s_dqkv, s_small, s_small_bytes, s_gemm, s_gemm_bytes, s_nt_bytes = 0;
@@ -357,6 +366,66 @@ int block_backward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const fl
   return fold_flush(sink, s);
 }
 
+// Last decoder block in compact-tail mode: LN1 / qkv / attention on every row, then the masked patches' rows of the attention
+// output and of the residual stream are gathered (tail_rows) and proj / LN2 / MLP run on Mc rows.  h_out_c [Mc, d].
+int block_forward_tail(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const float* h_in, float* h_out_c, hipStream_t s) {
+  const int B = p->B, N = p->Nd, d = p->Dd, m = p->Mlpd, heads = p->Hd, M = B * N, Mc = p->Mc;
+  unsigned char* ws = p->ws;
+  const int32_t* rows = (const int32_t*)(ws + p->a_tail_rows);
+  float* hin_c = (float*)(ws + p->s_dh);  // (a scratch buffer of the backward: free during the forward)
+  RC(hct_layernorm_fwd(h_in, p->pf(bp.ln1_w), p->pf(bp.ln1_b), M, d, 1e-5f, ws + ba.x1, p->dt, (float*)(ws + ba.mean1), (float*)(ws + ba.rstd1), s));
+  RC(linear_fwd(p, ws + ba.x1, M, d, bp.qkv_w, bp.qkv_b, 3 * d, ws + ba.qkv, p->dt, HCT_ACT_NONE, nullptr, nullptr, s));
+  RC(hct_attention_fwd(ws + ba.qkv, B, N, heads, d / heads, p->dt, ws + ba.o, (float*)(ws + ba.lse), s));
+  RC(hct_gather_rows(ws + ba.o, rows, Mc, (int)(d * p->esz()), ws + p->a_oc, s));
+  RC(hct_gather_rows(h_in, rows, Mc, d * 4, hin_c, s));
+  RC(linear_fwd(p, ws + p->a_oc, Mc, d, bp.proj_w, bp.proj_b, d, ws + ba.h_mid, HCT_F32, HCT_ACT_NONE, nullptr, hin_c, s));
+  RC(hct_layernorm_fwd((const float*)(ws + ba.h_mid), p->pf(bp.ln2_w), p->pf(bp.ln2_b), Mc, d, 1e-5f, ws + ba.x2, p->dt, (float*)(ws + ba.mean2), (float*)(ws + ba.rstd2), s));
+  RC(linear_fwd(p, ws + ba.x2, Mc, d, bp.fc1_w, bp.fc1_b, m, ws + ba.g, p->dt, kActFc1, ws + ba.u, nullptr, s));
+  RC(linear_fwd(p, ws + ba.g, Mc, m, bp.fc2_w, bp.fc2_b, d, h_out_c, HCT_F32, HCT_ACT_NONE, nullptr, (const float*)(ws + ba.h_mid), s));
+  return 0;
+}
+
+// Its backward.  in: s_dhc (fp32 [Mc,d]) + s_dh_shadow (compute dtype, compact rows) = gradient wrt the block's compact output.
+// out: s_dh / s_dh_shadow hold the gradient wrt the block input on ALL rows.
+int block_backward_tail(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const float* h_in, int prev_fc2_b, hipStream_t s) {
+  const int B = p->B, N = p->Nd, d = p->Dd, m = p->Mlpd, heads = p->Hd, M = B * N, Mc = p->Mc;
+  unsigned char* ws = p->ws;
+  float* dh = (float*)(ws + p->s_dh);
+  float* dhc = (float*)(ws + p->s_dhc);
+  void* dhs = ws + p->s_dh_shadow;
+  void* dbig = ws + p->s_dbig;
+  void* dx = ws + p->s_dx;
+  void* d_o = ws + p->s_do;
+  void* dqkv = ws + p->s_dqkv;
+  const int32_t* inv = (const int32_t*)(ws + p->a_tail_inv);
+  FoldSink sink;
+  struct SinkScope {
+    FoldSink* prev;
+    explicit SinkScope(FoldSink* s_) : prev(g_fold_sink) { g_fold_sink = s_; }
+    ~SinkScope() { g_fold_sink = prev; }
+  } scope(defer_folds() ? &sink : g_fold_sink);
+  // MLP branch, compact rows
+  RC(linear_wgrad(p, dhs, ws + ba.g, Mc, d, m, bp.fc2_w, -1, s));
+  RC(linear_dgrad(p, dhs, Mc, d, bp.fc2_w, m, dbig, kActFc2Dgrad, ws + ba.u, s, p->gf(bp.fc1_b)));
+  RC(linear_wgrad(p, dbig, ws + ba.x2, Mc, m, d, bp.fc1_w, -1, s));
+  RC(linear_dgrad(p, dbig, Mc, m, bp.fc1_w, d, dx, HCT_ACT_NONE, nullptr, s));
+  RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + ba.h_mid), (const float*)(ws + ba.mean2), (const float*)(ws + ba.rstd2),
+                       p->pf(bp.ln2_w), dhc, Mc, d, dhc, dhs, p->dt, p->gf(bp.ln2_w), p->gf(bp.ln2_b), p->gf(bp.proj_b), ws + p->s_fold_a,
+                       p->s_fold_bytes, s));
+  // attention branch: proj on the compact rows, its input gradient scattered back (zeros on the rows the loss never sees)
+  RC(linear_wgrad(p, dhs, ws + p->a_oc, Mc, d, d, bp.proj_w, -1, s));
+  RC(linear_dgrad(p, dhs, Mc, d, bp.proj_w, d, dx, HCT_ACT_NONE, nullptr, s));
+  RC(hct_gather_rows(dx, inv, M, (int)(d * p->esz()), d_o, s));
+  RC(hct_attention_bwd(ws + ba.qkv, ws + ba.o, d_o, (const float*)(ws + ba.lse), B, N, heads, d / heads, p->dt, dqkv, s));
+  RC(linear_wgrad(p, dqkv, ws + ba.x1, M, 3 * d, d, bp.qkv_w, bp.qkv_b, s));
+  RC(linear_dgrad(p, dqkv, M, 3 * d, bp.qkv_w, d, dx, HCT_ACT_NONE, nullptr, s));
+  // residual gradient of row r = the compact gradient's row tail_inv[r], nothing for the class token and the kept patches
+  RC(hct_layernorm_bwd_mapped(dx, p->dt, h_in, (const float*)(ws + ba.mean1), (const float*)(ws + ba.rstd1), p->pf(bp.ln1_w), dhc, inv, M, d,
+                              dh, dhs, p->dt, p->gf(bp.ln1_w), p->gf(bp.ln1_b), prev_fc2_b >= 0 ? p->gf(prev_fc2_b) : nullptr, ws + p->s_fold_b,
+                              p->s_fold_bytes, s));
+  return fold_flush(sink, s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -453,6 +522,12 @@ hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int comput
   p->a_yn_rstd = w.take(Md * 4);
   p->a_pred = w.take(Md * p->pd * es);
   p->a_dpred = w.take(Md * p->pd * es);
+  p->Mc = p->vit ? 0 : batch * (p->L - p->K);
+  p->tail_ok = !p->vit && p->cfg.decoder_depth >= 1 && p->Mc > 0 && (Dd * es) % 16 == 0;
+  p->a_tail_rows = w.take((size_t)p->Mc * 4);
+  p->a_tail_inv = w.take(Md * 4);
+  p->a_oc = w.take((size_t)p->Mc * Dd * es);
+  p->s_dhc = w.take((size_t)p->Mc * Dd * 4);
   const size_t Mx = Md > Me ? Md : Me, Dx = Dd > D ? Dd : D;
   const size_t mlpx = (size_t)(p->Mlp > p->Mlpd ? p->Mlp : p->Mlpd);
   p->s_dh = w.take(Mx * Dx * 4);
@@ -510,6 +585,7 @@ hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int comput
   reg("latent", p->a_latent, p->Me, p->D, p->dt);
   reg("dec_in", p->h_dec[0], p->Md, p->Dd, HCT_F32);
   for (int i = 0; i < p->cfg.decoder_depth; ++i) reg("dec" + std::to_string(i) + ".out", p->h_dec[i + 1], p->Md, p->Dd, HCT_F32);
+  reg("tail_rows", p->a_tail_rows, 1, p->Mc, 2);
   reg("pred_full", p->a_pred, p->Md, p->pd, p->dt);
   reg("dpred_full", p->a_dpred, p->Md, p->pd, p->dt);
   if (c->encoder_depth > 0) {
@@ -530,6 +606,11 @@ int64_t hct_mae_plan_param_elems(const hct_mae_plan* p) { return p->param_elems;
 int64_t hct_mae_plan_bf16_t_elems(const hct_mae_plan* p) { return p->bf16t_elems; }
 size_t hct_mae_plan_workspace_bytes(const hct_mae_plan* p) { return p->ws_bytes; }
 int hct_mae_plan_len_keep(const hct_mae_plan* p) { return p ? p->K : -1; }
+int hct_mae_plan_set_tail(hct_mae_plan* p, int compact) {
+  if (!p) return -1;
+  p->tail = compact != 0 && p->tail_ok;
+  return p->tail ? 1 : 0;
+}
 
 int hct_mae_plan_bind(hct_mae_plan* p, float* params, float* grads, void* params_bf16, void* params_bf16_t, void* workspace,
                       size_t workspace_bytes) {
@@ -592,18 +673,26 @@ int hct_mae_forward(hct_mae_plan* p, const void* x, int x_dtype, const float* no
   RC(linear_fwd(p, ws + p->a_latent, p->Me, p->D, p->p_de_w, p->p_de_b, p->Dd, ws + p->a_e, p->dt, HCT_ACT_NONE, nullptr, nullptr, s));
   RC(hct_decoder_assemble_fwd(ws + p->a_e, p->dt, p->pf(p->p_mask), p->pf(p->p_dcls), p->pf(p->p_dpos), ids_restore, B, p->L, p->K, p->Dd,
                               (float*)(ws + p->h_dec[0]), s));
-  for (int i = 0; i < c.decoder_depth; ++i)
-    RC(block_forward(p, p->dec[i], p->adec[i], (const float*)(ws + p->h_dec[i]), (float*)(ws + p->h_dec[i + 1]), B, p->Nd, p->Dd, p->Mlpd, p->Hd, s));
-  RC(hct_layernorm_fwd((const float*)(ws + p->h_dec[c.decoder_depth]), p->pf(p->p_dnorm_w), p->pf(p->p_dnorm_b), p->Md, p->Dd, 1e-5f,
+  const bool tail = p->tail && p->tail_ok;
+  p->tail_fwd = tail;
+  if (tail) RC(hct_tail_rows(ids_restore, B, p->L, p->K, (int32_t*)(ws + p->a_tail_rows), (int32_t*)(ws + p->a_tail_inv), s));
+  for (int i = 0; i < c.decoder_depth; ++i) {
+    if (tail && i == c.decoder_depth - 1)
+      RC(block_forward_tail(p, p->dec[i], p->adec[i], (const float*)(ws + p->h_dec[i]), (float*)(ws + p->h_dec[i + 1]), s));
+    else
+      RC(block_forward(p, p->dec[i], p->adec[i], (const float*)(ws + p->h_dec[i]), (float*)(ws + p->h_dec[i + 1]), B, p->Nd, p->Dd, p->Mlpd, p->Hd, s));
+  }
+  const int Mt = tail ? p->Mc : p->Md;  // rows of the decoder's tail: the masked patches' (compact), or all
+  RC(hct_layernorm_fwd((const float*)(ws + p->h_dec[c.decoder_depth]), p->pf(p->p_dnorm_w), p->pf(p->p_dnorm_b), Mt, p->Dd, 1e-5f,
                        ws + p->a_ynorm, p->dt, (float*)(ws + p->a_yn_mean), (float*)(ws + p->a_yn_rstd), s));
-  RC(linear_fwd(p, ws + p->a_ynorm, p->Md, p->Dd, p->p_pred_w, p->p_pred_b, p->pd, ws + p->a_pred, p->dt, HCT_ACT_NONE, nullptr, nullptr, s));
+  RC(linear_fwd(p, ws + p->a_ynorm, Mt, p->Dd, p->p_pred_w, p->p_pred_b, p->pd, ws + p->a_pred, p->dt, HCT_ACT_NONE, nullptr, nullptr, s));
   // One pass over the volume and the prediction gives the loss and, in a training forward (grad_scale != 0), the seed of
   // the backward d(loss)/d(pred) * grad_scale as well (grad_scale = the data-parallel 1 / world_size, known on the host);
   // the incoming dLoss is a device scalar that is only known in the backward and is applied there if it is not 1.
   const bool train = grad_scale != 0.0f;
   RC(masked_mse_launch(ws + p->a_pred, p->dt, x, x_dtype, mask, B, c.in_chans, c.input_size, c.patch_size, c.norm_pix_loss,
                        (float)((int64_t)B * (p->L - p->K)), (float*)(ws + p->a_row_loss), loss, train ? ws + p->a_dpred : nullptr, nullptr,
-                       train ? grad_scale : 1.0f, s));
+                       train ? grad_scale : 1.0f, s, tail ? ids_shuffle : nullptr, p->K));
   p->fwd_done = true;
   p->dpred_done = train;
   return 0;
@@ -699,16 +788,20 @@ int hct_mae_backward_stage(hct_mae_plan* p, int stage, void* stream) {
   void* small = ws + p->s_small;
   if (stage == 0) {  // loss seed -> decoder_pred -> decoder_norm
     if (!p->dpred_done) { set_error("hct_mae_backward_stage: the last forward ran without grad_scale (inference forward)"); return HCT_E_STATE; }
-    if (p->dloss) RC(scale_unless_one(ws + p->a_dpred, p->dt, (int64_t)p->Md * p->pd, p->dloss, s));
-    RC(linear_wgrad(p, ws + p->a_dpred, ws + p->a_ynorm, p->Md, p->pd, p->Dd, p->p_pred_w, p->p_pred_b, s));
-    RC(linear_dgrad(p, ws + p->a_dpred, p->Md, p->pd, p->p_pred_w, p->Dd, dx, HCT_ACT_NONE, nullptr, s));
+    const int Mt = p->tail_fwd ? p->Mc : p->Md;                       // compact tail: the masked patches' rows only
+    float* dht = p->tail_fwd ? (float*)(ws + p->s_dhc) : dh;          // ... whose fp32 gradient has a buffer of its own
+    if (p->dloss) RC(scale_unless_one(ws + p->a_dpred, p->dt, (int64_t)Mt * p->pd, p->dloss, s));
+    RC(linear_wgrad(p, ws + p->a_dpred, ws + p->a_ynorm, Mt, p->pd, p->Dd, p->p_pred_w, p->p_pred_b, s));
+    RC(linear_dgrad(p, ws + p->a_dpred, Mt, p->pd, p->p_pred_w, p->Dd, dx, HCT_ACT_NONE, nullptr, s));
     RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + p->h_dec[nd]), (const float*)(ws + p->a_yn_mean), (const float*)(ws + p->a_yn_rstd),
-                         p->pf(p->p_dnorm_w), nullptr, p->Md, p->Dd, dh, dhs, p->dt, p->gf(p->p_dnorm_w), p->gf(p->p_dnorm_b),
+                         p->pf(p->p_dnorm_w), nullptr, Mt, p->Dd, dht, dhs, p->dt, p->gf(p->p_dnorm_w), p->gf(p->p_dnorm_b),
                          nd > 0 ? p->gf(p->dec[nd - 1].fc2_b) : nullptr, small, p->s_small_bytes, s));
     return 0;
   }
   if (stage <= nd) {
     const int i = nd - stage;
+    if (p->tail_fwd && i == nd - 1)
+      return block_backward_tail(p, p->dec[i], p->adec[i], (const float*)(ws + p->h_dec[i]), i > 0 ? p->dec[i - 1].fc2_b : -1, s);
     return block_backward(p, p->dec[i], p->adec[i], (const float*)(ws + p->h_dec[i]), B, p->Nd, p->Dd, p->Mlpd, p->Hd,
                           i > 0 ? p->dec[i - 1].fc2_b : -1, s);
   }

@@ -144,6 +144,9 @@ class _MAEFunction(torch.autograd.Function):
         plan = model._plan_for(x.shape[0])
         st = _lib.stream_ptr()
         model._ensure_weights_fresh(plan, st)
+        # a training forward needs no prediction for the kept patches (the loss drops them, mae.py:298-299): the decoder's tail
+        # then runs on the masked patches' rows only, unless the caller asked for the full prediction (`full_pred`)
+        plan.tail = bool(plan.lib.hct_mae_plan_set_tail(plan.handle, int(train and not getattr(model, "full_pred", False))) == 1)
         # training forward: the loss pass also leaves d(loss)/d(pred) (scaled by 1/world under data parallelism) for the backward
         xdt = _lib.HCT_F16 if x.dtype == torch.float16 else HCT_F32
         _lib.check(plan.lib.hct_mae_forward(plan.handle, x.data_ptr(), xdt, noise.data_ptr(), plan.loss.data_ptr(),
@@ -406,6 +409,7 @@ class MaskedAutoencoderViT(FlatPlanModule):
             norm_pix_loss=int(bool(norm_pix_loss)), use_bias=int(bool(use_bias)))
         self._dt = HCT_BF16 if compute_dtype == "bf16" else HCT_F32
         self.len_keep = int(num_patches * (1 - mask_ratio))  # mae.py:205
+        self.full_pred = False  # True: training forwards also predict the kept patches (parity tests, reconstructions)
 
         self._init_flat_state()
         self.initialize_weights()
@@ -473,9 +477,27 @@ class MaskedAutoencoderViT(FlatPlanModule):
         return self._plan_for(batch).activation(name)
 
     def last_pred(self, batch: int) -> torch.Tensor:
-        """pred [B, L, pd] of the last forward (mae.py:272-273), fp32."""
+        """pred [B, L, pd] of the last forward (mae.py:272-273), fp32.  A training forward predicts the masked patches only
+        (the loss takes no other row, mae.py:298-299) unless `model.full_pred = True`; forwards under `torch.no_grad()` always
+        predict every patch."""
+        plan = self._plan_for(batch)
+        if getattr(plan, "tail", False):
+            raise HctError("the last forward was a training forward, which predicts only the masked patches: set model.full_pred = True "
+                           "(or run the forward under torch.no_grad()) to get the prediction of every patch")
         full = self.activation("pred_full", batch).float()
         return full.view(batch, self.num_patches + 1, -1)[:, 1:, :]
+
+    def last_pred_masked(self, batch: int):
+        """(rows, pred): prediction rows of the masked patches of the last forward and their row index b * (L + 1) + 1 + patch in
+        the decoder layout -- available after every forward (in a training forward these are the only rows computed)."""
+        plan = self._plan_for(batch)
+        n = batch * (self.num_patches - self.len_keep)
+        if getattr(plan, "tail", False):
+            rows = plan.activation("tail_rows").view(-1)[:n].long()
+            return rows, self.activation("pred_full", batch)[:n].float()
+        ids_restore = self.activation("ids_restore", batch).long()
+        rows = ((ids_restore >= self.len_keep).nonzero()[:, 0] * (self.num_patches + 1) + 1 + (ids_restore >= self.len_keep).nonzero()[:, 1])
+        return rows, self.activation("pred_full", batch).float()[rows]
 
     def last_mask(self, batch: int) -> torch.Tensor:
         return self.activation("mask", batch)

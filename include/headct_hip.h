@@ -94,6 +94,17 @@ size_t hct_gemm_nt_flags_offset(size_t workspace_bytes);
  * with the backward) have somewhere to run; set by the data-parallel wrapper when world_size > 1. */
 void hct_set_cu_reserve(int n);
 int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, void* stream);
+/* Grouped weight gradients: n "TN" products dW_i[M_i,N_i] = alpha_i * A_i[K_i,M_i]^T . B_i[K_i,N_i] (bf16 operands, fp32 C, no
+ * epilogue extras) in ONE persistent launch, each 256x256 output tile reducing over ALL K_i rows (no split partials, no fold
+ * launch); the partly filled last round of tiles is shared out by reduction range with a fixed summation order
+ * (bit-reproducible).  The weight gradients of a training step do not feed its backward chain, so the model driver collects
+ * those of several blocks and runs them here (the reference computes each inside autograd's backward of its Linear,
+ * attentionblock.py:41-42, MLPBlock).  `prepare` writes the job table into the workspace and zeroes its flags (once per set of
+ * pointers / shapes, stream-ordered); `run` launches on the prepared table (same jobs array).  workspace: 256-byte aligned,
+ * hct_gemm_tn_group_workspace_bytes(n), used by nothing else between prepare and the last run.                              */
+size_t hct_gemm_tn_group_workspace_bytes(int n_jobs);
+int hct_gemm_tn_group_prepare(const hct_gemm_args* jobs, int n_jobs, void* workspace, size_t workspace_bytes, void* stream);
+int hct_gemm_tn_group_run(const hct_gemm_args* jobs, int n_jobs, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Random masking from supplied noise (mae.py:204-216).  Stable ranking: ties -> lower index first.
@@ -136,6 +147,18 @@ int hct_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
                       const float* gamma, const float* dres, int rows, int D, float* dx, void* dx_shadow,
                       int shadow_dtype, float* dgamma, float* dbeta, float* dcolsum, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* The same with the residual gradient taken from a COMPACT matrix: row r adds dres[dres_rows[r]], nothing where
+ * dres_rows[r] < 0 (dres_rows == NULL: as hct_layernorm_bwd).  dres must not alias dx then.  Used by the plan where the
+ * tail of the MAE decoder runs on the masked patches' rows only (mae.py:298-299: the loss takes no other row).      */
+int hct_layernorm_bwd_mapped(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
+                             const float* gamma, const float* dres, const int32_t* dres_rows, int rows, int D, float* dx,
+                             void* dx_shadow, int shadow_dtype, float* dgamma, float* dbeta, float* dcolsum, void* workspace,
+                             size_t workspace_bytes, void* stream);
+/* Rows of the [B, L+1] decoder layout that hold masked patches (mae.py:207-214: ids_restore[b, l] >= K), per volume in
+ * shuffle order: tail_rows [B*(L-K)] and its inverse tail_inv [B*(L+1)] (-1 for the class token and the kept patches). */
+int hct_tail_rows(const int32_t* ids_restore, int B, int L, int K, int32_t* tail_rows, int32_t* tail_inv, void* stream);
+/* dst row r = src row idx[r], zeros where idx[r] < 0; rows of row_bytes (multiple of 16) bytes, 16-byte aligned bases.  */
+int hct_gather_rows(const void* src, const int32_t* idx, int n_rows, int row_bytes, void* dst, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-head self-attention, no mask, scale dh^-1/2 (attentionblock.py:54-62,
@@ -344,6 +367,14 @@ int64_t hct_mae_plan_param_elems(const hct_mae_plan*);     /* flat fp32 params /
 int64_t hct_mae_plan_bf16_t_elems(const hct_mae_plan*);    /* transposed-bf16 weight buffer length      */
 size_t hct_mae_plan_workspace_bytes(const hct_mae_plan*);  /* activations + scratch                      */
 int hct_mae_plan_len_keep(const hct_mae_plan*);            /* visible patches per volume = int(L * (1 - mask_ratio)) */
+/* Compact tail (MAE plans): the loss takes only the masked patches' rows (mae.py:298-299), so with compact != 0 the next
+ * forwards run everything behind the last decoder block's attention (its proj / MLP, decoder_norm, decoder_pred, the loss)
+ * and the matching backward on those B*(L-K) rows alone.  Loss and every parameter gradient are those of the full
+ * computation; the activations "dec<last>.out", "pred_full", "dpred_full" then hold the compact rows (row j of volume b =
+ * decoder row tail_rows[b*(L-K)+j], activation "tail_rows") and the kept patches have NO prediction: leave it off (the
+ * default) for a forward whose reconstruction of every patch is wanted.  Returns the mode in effect (0 where the geometry
+ * does not allow it), < 0 on a null plan.                                                                                */
+int hct_mae_plan_set_tail(hct_mae_plan*, int compact);
 /* bind caller-owned device buffers. params_bf16 / params_bf16_t may be NULL in HCT_F32 mode. */
 int hct_mae_plan_bind(hct_mae_plan*, float* params, float* grads, void* params_bf16, void* params_bf16_t,
                       void* workspace, size_t workspace_bytes);
@@ -389,6 +420,13 @@ void hct_prof_enable(int mask); /* bit i enables kernel class i; 0 = off */
 void hct_prof_reset(void);
 int hct_prof_read(int id, double* total_ms, int64_t* launches, double* work);
 int hct_prof_read_bytes(int id, double* bytes); /* algorithmic bytes (operands read once + outputs written once) of those launches */
+/* per-shape view of the same records (GEMM classes): one entry per distinct (M, N, K, epilogue mode, tiles, stream-K tiles) */
+typedef struct hct_prof_shape {
+  int M, N, K, mode, tiles, sk_tiles;
+  int64_t launches;
+  double total_ms, work, bytes;
+} hct_prof_shape;
+int hct_prof_shapes(int id, hct_prof_shape* out, int cap); /* returns the number of distinct keys, -1 on a HIP error */
 /* testing hook, attention kernel choice (tests and scripts/ab_step.py only):
  *   0 / 1        default / every call through the fp32-math kernels;   2 / 3  online-softmax / full-row MFMA forward
  *   10 + bits    backward experiment bits (4 single-phase, 8 four-wave two-phase, 32 two-phase everywhere, 64 one wave per

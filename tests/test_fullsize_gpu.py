@@ -36,7 +36,7 @@ def _step(model, x, noise):
 def test_full_size_step_properties(lib, cuda):
     B = 256
     params = O.make_params(CFG, 3)
-    model = build_hip_model(CFG, params, cuda, "bf16").train()
+    model = build_hip_model(CFG, params, cuda, "bf16", full_pred=False).train()  # the module default = what bench.py times
     x, noise = _inputs(B, cuda)
     loss1, g1 = _step(model, x, noise)
     loss2, g2 = _step(model, x, noise)
@@ -56,7 +56,7 @@ def test_full_size_step_properties(lib, cuda):
 
     # linearity in the batch: every sample has the same number of masked patches, so the loss is the mean of the halves
     # and every gradient the mean of the halves' gradients (fp32 accumulation order differs: split sizes of the wgrad)
-    half = build_hip_model(CFG, params, cuda, "bf16").train()
+    half = build_hip_model(CFG, params, cuda, "bf16", full_pred=False).train()
     la, ga = _step(half, x[:128], noise[:128])
     lb, gb = _step(half, x[128:], noise[128:])
     assert abs(loss1 - 0.5 * (la + lb)) < 2e-5 * abs(loss1)
@@ -131,7 +131,7 @@ def test_vitl_full_depth_step_properties(lib, cuda):
     g.manual_seed(17)
     x = torch.rand(B, 1, S, S, S, device=cuda, generator=g)
     noise = torch.rand(B, L, device=cuda, generator=g)
-    model = build_hip_model(cfg, params, cuda, "bf16").train()
+    model = build_hip_model(cfg, params, cuda, "bf16", full_pred=False).train()
     loss1, g1 = _step(model, x, noise)
     loss2, g2 = _step(model, x, noise)
     assert loss1 == loss2 and all(torch.equal(g1[k], g2[k]) for k in g1), "the ViT-L step is not bit-reproducible"
@@ -142,7 +142,7 @@ def test_vitl_full_depth_step_properties(lib, cuda):
     assert float(mask.sum()) == B * (L - K)
     assert torch.equal(torch.sort(ids_restore, dim=1).values, torch.arange(L, device=cuda).expand(B, L))
     assert torch.equal(mask == 0, ids_restore < K)
-    half = build_hip_model(cfg, params, cuda, "bf16").train()
+    half = build_hip_model(cfg, params, cuda, "bf16", full_pred=False).train()
     la, ga = _step(half, x[:8], noise[:8])
     lb, gb = _step(half, x[8:], noise[8:])
     assert abs(loss1 - 0.5 * (la + lb)) < 2e-5 * abs(loss1)

@@ -302,6 +302,63 @@ def test_mask_rank_with_ties(lib, cuda):
     assert torch.equal(ids[1].cpu().long(), torch.arange(L))
 
 
+def test_tail_rows_gather_and_mapped_layernorm_bwd(lib, cuda):
+    """The three pieces of the compact decoder tail: hct_tail_rows (rows of the masked patches in shuffle order + inverse),
+    hct_gather_rows (gather, and scatter-with-zeros through the inverse map; bit-exact copies), hct_layernorm_bwd_mapped (residual
+    gradient taken from the compact matrix through the inverse map)."""
+    B, L, K, D = 3, 216, 54, 768
+    noise = torch.rand(B, L)
+    shuffle = torch.argsort(noise, dim=1, stable=True)
+    restore = torch.argsort(shuffle, dim=1, stable=True).to(torch.int32).to(cuda)
+    Lm, Md = L - K, B * (L + 1)
+    rows = torch.empty(B * Lm, dtype=torch.int32, device=cuda)
+    inv = torch.empty(Md, dtype=torch.int32, device=cuda)
+    _lib.check(lib.hct_tail_rows(restore.data_ptr(), B, L, K, rows.data_ptr(), inv.data_ptr(), _st()), "tail_rows")
+    want_rows = (torch.arange(B)[:, None] * (L + 1) + 1 + shuffle[:, K:]).reshape(-1)
+    assert torch.equal(rows.cpu().long(), want_rows)
+    want_inv = torch.full((Md,), -1, dtype=torch.long)
+    want_inv[want_rows] = torch.arange(B * Lm)
+    assert torch.equal(inv.cpu().long(), want_inv)
+    for dtype in (torch.bfloat16, torch.float32):
+        src = _rand((Md, D), cuda, dtype, 5)
+        comp = torch.empty(B * Lm, D, dtype=dtype, device=cuda)
+        _lib.check(lib.hct_gather_rows(src.data_ptr(), rows.data_ptr(), B * Lm, D * src.element_size(), comp.data_ptr(), _st()), "gather")
+        assert torch.equal(comp, src[rows.long()])
+        back = torch.full((Md, D), 7.0, dtype=dtype, device=cuda)
+        _lib.check(lib.hct_gather_rows(comp.data_ptr(), inv.data_ptr(), Md, D * src.element_size(), back.data_ptr(), _st()), "scatter")
+        want = torch.zeros_like(src)
+        want[rows.long()] = src[rows.long()]
+        assert torch.equal(back, want)
+    # LayerNorm backward with the residual gradient read through the inverse map == the plain call on the scattered matrix
+    x, dy = _rand((Md, D), cuda, torch.float32, 11), _rand((Md, D), cuda, torch.bfloat16, 12)
+    gamma = _rand((D,), cuda, torch.float32, 13)
+    dres_c = _rand((B * Lm, D), cuda, torch.float32, 14)
+    dres_full = torch.zeros(Md, D, device=cuda)
+    dres_full[rows.long()] = dres_c
+    mean, var = x.mean(1), x.var(1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    ws = torch.empty(lib.hct_layernorm_bwd_workspace_bytes(Md, D), dtype=torch.uint8, device=cuda)
+    outs = []
+    for mapped in (False, True):
+        dx = torch.empty(Md, D, device=cuda)
+        shadow = torch.empty(Md, D, dtype=torch.bfloat16, device=cuda)
+        dg, db, dc = (torch.empty(D, device=cuda) for _ in range(3))
+        if mapped:
+            _lib.check(lib.hct_layernorm_bwd_mapped(dy.data_ptr(), _dt(dy), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                                    dres_c.data_ptr(), inv.data_ptr(), Md, D, dx.data_ptr(), shadow.data_ptr(), _dt(shadow),
+                                                    dg.data_ptr(), db.data_ptr(), dc.data_ptr(), ws.data_ptr(), ws.numel(), _st()), "ln bwd mapped")
+        else:
+            _lib.check(lib.hct_layernorm_bwd(dy.data_ptr(), _dt(dy), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                             dres_full.data_ptr(), Md, D, dx.data_ptr(), shadow.data_ptr(), _dt(shadow), dg.data_ptr(),
+                                             db.data_ptr(), dc.data_ptr(), ws.data_ptr(), ws.numel(), _st()), "ln bwd")
+        outs.append((dx, shadow, dg, db, dc))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # a mapped residual gradient that aliases the output is refused
+    assert lib.hct_layernorm_bwd_mapped(dy.data_ptr(), _dt(dy), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
+                                        inv.data_ptr(), Md, D, dx.data_ptr(), None, 0, dg.data_ptr(), db.data_ptr(), None, ws.data_ptr(), ws.numel(), _st()) != 0
+
+
 def test_colsum_cast_transpose(lib, cuda):
     for rows, cols, dtype in ((1000, 768, torch.bfloat16), (37, 2304, torch.float32), (1, 4, torch.float32)):
         x = _rand((rows, cols), cuda, dtype, 31)

@@ -93,6 +93,55 @@ def test_bf16_forward_backward_vs_oracle(lib, cuda, name, batch, seed):
     assert max(bad)[0] < 6e-2, sorted(bad)[-5:]
 
 
+@pytest.mark.parametrize("name,batch,seed", CASES)
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_compact_decoder_tail_vs_full_and_oracle(lib, cuda, name, batch, seed, dtype):
+    """The module's default training forward runs the decoder's tail (last block's proj / MLP, decoder_norm, decoder_pred, loss) on
+    the masked patches' rows only -- the loss takes no other row, mae.py:298-299.  Loss and EVERY gradient must be those of the
+    full computation (same kernels on a row subset: 1e-5 fp32; bf16 differs by summation order of the column sums only), and
+    the masked rows of pred / of the last block's output must match the oracle's."""
+    cfg = O.CONFIGS[name]
+    params = O.make_params(cfg, seed)
+    x, noise = O.make_volume(cfg, batch, seed), O.make_noise(cfg, batch, seed)
+    full = build_hip_model(cfg, params, cuda, dtype, full_pred=True)
+    tail = build_hip_model(cfg, params, cuda, dtype, full_pred=False)
+    out = {}
+    for key, m in (("full", full), ("tail", tail)):
+        m.train()
+        loss, _, _ = m(x.to(cuda), noise=noise.to(cuda))
+        loss.backward()
+        torch.cuda.synchronize()
+        out[key] = (float(loss), grads_by_name(m))
+    tol = 1e-5 if dtype == "fp32" else 2e-3
+    assert abs(out["tail"][0] - out["full"][0]) <= tol * abs(out["full"][0])
+    assert set(out["tail"][1]) == set(out["full"][1])
+    for k, g in out["full"][1].items():
+        if k.endswith("qkv.bias"):
+            assert (out["tail"][1][k] - g).abs().max() <= 1e-6 + tol * g.abs().max(), k
+        else:
+            assert rel_err(out["tail"][1][k], g) < tol, k
+    with pytest.raises(Exception):
+        tail.last_pred(batch)  # no prediction exists for the kept patches
+    # masked rows: identical row sets, and the values of the full run / the oracle
+    rows_t, pred_t = tail.last_pred_masked(batch)
+    rows_f, pred_f = full.last_pred_masked(batch)
+    order_t, order_f = torch.argsort(rows_t), torch.argsort(rows_f)
+    assert torch.equal(rows_t[order_t], rows_f[order_f])
+    assert rel_err(pred_t[order_t], pred_f[order_f]) < (1e-5 if dtype == "fp32" else 1e-2)
+    if dtype == "fp32":
+        o_loss, o_pred, o_mask, o_grads, o_inter = O.forward_backward(cfg, params, x, noise, want_inter=True)
+        L = tail.num_patches
+        b, t = rows_t.cpu() // (L + 1), rows_t.cpu() % (L + 1)
+        assert bool((t >= 1).all()) and bool((o_mask[b, t - 1] == 1).all()) and rows_t.numel() == int(o_mask.sum())
+        assert rel_err(pred_t.cpu(), o_pred[b, t - 1]) < 1e-3
+        last = o_inter[f"dec{cfg.decoder_depth - 1}.out"]
+        got = tail.activation(f"dec{cfg.decoder_depth - 1}.out", batch)[:rows_t.numel()].cpu()
+        assert rel_err(got, last.reshape(-1, last.shape[-1])[rows_t.cpu()]) < 1e-3
+        assert abs(out["tail"][0] - float(o_loss)) / abs(float(o_loss)) < 1e-3
+        worst = max((rel_err(out["tail"][1][k], o_grads[k]), k) for k in o_grads if not k.endswith("qkv.bias"))
+        assert worst[0] < 1e-3, worst
+
+
 def test_train_curve_fp32_vs_golden(lib, cuda):
     """N-step loss curve, LR values and parameters after training vs the reference's own train_one_epoch."""
     from headct_foundation_amd.optim import HipAdamW, clip_gradients
@@ -258,7 +307,7 @@ def test_odd_and_changing_batch_sizes_vs_oracle(lib, cuda, name, dtype, tol_loss
     short last batch of an epoch produces them: each batch size gets its own plan; loss and gradients vs the oracle."""
     cfg = O.CONFIGS[name]
     params = O.make_params(cfg, 0)
-    model = build_hip_model(cfg, params, cuda, dtype)
+    model = build_hip_model(cfg, params, cuda, dtype, full_pred=False)  # the module default (compact decoder tail)
     model.train()
     for batch in (3, 1, 5, 3):
         x, noise = O.make_volume(cfg, batch, 20 + batch), O.make_noise(cfg, batch, 20 + batch)
@@ -347,7 +396,7 @@ def test_bf16_loss_curve_vs_oracle(lib, cuda, name, steps):
     params = O.make_params(cfg, 7)
     st32 = O.TrainState({k: v.clone() for k, v in params.items()})
     st16 = O.TrainState({k: v.clone() for k, v in params.items()})
-    model = build_hip_model(cfg, params, cuda, "bf16").train()
+    model = build_hip_model(cfg, params, cuda, "bf16", full_pred=False).train()  # the module default, as bench.py / the engine run it
     opt = HipAdamW(model, lr=hp["base_lr"], weight_decay=hp["weight_decay"], betas=(0.9, 0.95))
     sched = get_cosine_schedule_with_warmup(opt, hp["warmup"], hp["total"], lr_end=hp["min_lr"])
     hip, ref32, ref16 = [], [], []

@@ -26,10 +26,13 @@ def sample_of(t: torch.Tensor, entry):
     return f[idx], torch.tensor(entry["val"], dtype=torch.float64), float(f.norm()), entry["l2"]
 
 
-def build_hip_model(cfg: O.MAEConfig, params, device, compute_dtype="fp32"):
+def build_hip_model(cfg: O.MAEConfig, params, device, compute_dtype="fp32", full_pred=True):
+    """full_pred=True: training forwards also predict the kept patches, so that pred and the last decoder block's output can be
+    compared row by row with the oracle; False = the module's default (compact decoder tail: masked patches only)."""
     from headct_foundation_amd import MaskedAutoencoderViT
     m = MaskedAutoencoderViT(**cfg.ctor_kwargs(), compute_dtype=compute_dtype)
     missing = m.load_state_dict(params, strict=True)
+    m.full_pred = full_pred
     return m.to(device)
 
 
