@@ -41,6 +41,8 @@ int check_hip(hipError_t e, const char* what);
 int masked_mse_launch(const void* pred, int pred_dtype, const void* x, int x_dtype, const float* mask, int B, int C, int S, int P,
                       int norm_pix, float mask_sum, float* row_loss, float* loss, void* dpred, const float* dpred_scale,
                       float host_scale, hipStream_t s, const int32_t* masked_ids = nullptr, int K = 0);  // masked_ids: compact-row form
+// host-side test: can this product join a grouped weight-gradient launch (hct_gemm_tn_group_*; gemm.hip)
+bool tn_group_ok(const hct_gemm_args* a);
 // buf[i] *= *scale unless *scale == 1 (every block then leaves after one scalar load)
 int scale_unless_one(void* buf, int dtype, int64_t n, const float* scale, hipStream_t s);
 // out[d] = sum_{b < nblk} partial[b*D + d]  (fixed order; elementwise.hip)

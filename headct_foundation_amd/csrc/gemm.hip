@@ -1798,751 +1798,6 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob*
     }
   };
   auto next_item = [&]() -> bool {
-    if (SK && it_owner) {
-      take_item(it_owner);
-      it_owner = 0;
-      return true;
-    }
-    if (vb < ntiles - sk_tiles) {
-      set_tile_id(dp_id(vb), 0);
-      cit = (uint32_t)P << 18;
-      vb += gridDim.x;
-      return true;
-    }
-    return false;
-  };
-  if (SK && it_first) take_item(it_first);
-  else if (!next_item()) return;  // (only with stream-K: more workgroups than K ranges and no whole tiles)
-  stage_pair(0);
-  if (kTwoPairs) {
-    stage_pair(2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile: no epilogue behind the pairs to leave in flight
-  }
-  int younger = 0;  // what this wave has issued since the current item's pair (0,1): see land_top
-  while (true) {
-    HCT_STAMP(0);
-    const int cm0 = m0, cn0 = n0;  // item being computed (next_item below moves m0/n0 to the next one)
-    const uint32_t item = cit;
-    const int cns = SK ? (int)((item >> 18) & 1023) * 2 : nk;  // stages of this item
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    // nk is even and >= 4 (host dispatch: K % 64 == 0, K >= 128).  Ring of 5 stage buffers; pair (0,1) was issued before
-    // the previous tile's epilogue.  Buffers 3 and 4 were that epilogue's patches: once every wave is through with them
-    // (barrier) pair (2,3) may go.  Pair (0,1) is older than the epilogue's loads/stores and than pair (2,3) (vmcnt retires
-    // in issue order), so allowing the 8 youngest operations to be outstanding means (0,1) has landed.
-    if (kTwoPairs) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kEpiOps) : "memory");  // pairs (0,1), (2,3): older than the previous epilogue's operations
-      __builtin_amdgcn_s_barrier();                                    // ... of every wave; and every wave is done with its patch
-    } else {
-      __builtin_amdgcn_s_barrier();
-      stage_pair(2);
-      land_top(younger);
-    }
-    HCT_STAMP(1);
-    rd_a(0, a0);
-    rd_b(0, 0, b_lo);
-    // Steady state, two K-steps per trip.  Even step t: no synchronisation at all (pair (t, t+1) became visible at the
-    // previous odd step).  Odd step t+1: pair (t+2, t+3), issued two steps ago, must have landed; every wave is then past
-    // its reads of stages t-1 and t, whose buffers take pair (t+4, t+5).
-    int t = 0;
-    for (; t + 5 < cns; t += 2) {
-      rd_b(t, 1, b_hi);
-      mma(0, a0, b_lo);
-      rd_a(t + 1, a1);
-      rd_b(t + 1, 0, b_lo);
-      mma(1, a0, b_hi);
-      rd_b(t + 1, 1, b_hi);
-      mma(0, a1, b_lo);
-      land_first(t);
-      stage_pair(t + 4);
-      rd_a(t + 2, a0);
-      rd_b(t + 2, 0, b_lo);
-      mma(1, a1, b_hi);
-    }
-    // t == cns - 4: every stage of the item has been issued
-    rd_b(t, 1, b_hi);
-    mma(0, a0, b_lo);
-    rd_a(t + 1, a1);
-    rd_b(t + 1, 0, b_lo);
-    mma(1, a0, b_hi);
-    rd_b(t + 1, 1, b_hi);
-    mma(0, a1, b_lo);
-    land_first(t);  // pair (cns-2, cns-1)
-    rd_a(t + 2, a0);
-    rd_b(t + 2, 0, b_lo);
-    mma(1, a1, b_hi);
-    rd_b(t + 2, 1, b_hi);
-    mma(0, a0, b_lo);
-    rd_a(t + 3, a1);
-    rd_b(t + 3, 0, b_lo);
-    mma(1, a0, b_hi);
-    // Bias of this lane's columns: requested here, with nothing else outstanding (every stage has landed) and the a0 fragments
-    // dead, and pinned as resident after the last MFMA group -- part of its L2 round trip runs under the two groups in between.
-    // hipcc cannot count the asm LDS-DMA operations, so a wait it generated for this load after the next tile's prefetch would
-    // wait for that prefetch.
-    TileBias bv = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-    TileBias bh[2] = {bv, bv};
-    if (MODE != EPI_GENERIC) tile_bias_halves<MODE>(e, cn0, wn * 128, lane, N, bh);
-    rd_b(t + 3, 1, b_hi);
-    mma(0, a1, b_lo);
-    mma(1, a1, b_hi);
-
-    __builtin_amdgcn_s_barrier();  // every wave has its last fragments in registers: the whole ring is free
-    HCT_STAMP(2);
-    if (MODE != EPI_GENERIC) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (EpiTraits<MODE>::wide) asm volatile("" : "+v"(bh[h].lo), "+v"(bh[h].hi));
-        else asm volatile("" : "+v"(bh[h].lo));
-      }
-    }
-    const bool more = next_item();
-    if (more) {  // prefetch the next item's first pair(s) of stages (ring buffers 0, 1 [, 2, 3]) under this item's epilogue
-      stage_pair(0);
-      if (kTwoPairs) stage_pair(2);
-    }
-    if (SK && ((item >> 8) & 1023)) {
-      // FOLLOWER piece: the raw accumulators leave in register order (1 KiB per store instruction), write-through (sc1) like
-      // the wgrad's split partials -- a write-through store needs no release fence -- then ONE flag per workgroup
-      const __amdgpu_buffer_rsrc_t rs =
-          __builtin_amdgcn_make_buffer_rsrc(sk_ws + kSkHeadBytes + (size_t)blockIdx.x * kSkSlabBytes, 0, (uint32_t)kSkSlabBytes, 0x00020000);
-      int ln = lane;
-      asm volatile("" : "+v"(ln));  // (not hoisted out of the persistent loop: a register there costs a spill in the main loop)
-      const uint32_t off0 = (uint32_t)(wave * 32768 + ln * 16);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, off0 + (uint32_t)((i * 8 + j) * 1024), 0, 16);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0)  // flag = launch sequence number | the XCD this workgroup really runs on
-        __hip_atomic_store((unsigned*)sk_ws + blockIdx.x, (sk_seq << 4) | xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      younger = 0;  // (everything was drained for the flag)
-    } else {
-      younger = 1;
-      if (SK && ((item >> 28) & 7)) {
-        // OWNER of a shared tile: add the followers' partials, workgroup order c+1, c+2, ...  Their bytes were stored
-        // write-through and drained before the flag; the poll is relaxed, ONE agent-scope acquire then drops this CU's stale
-        // lines before the plain loads (the protocol of the wgrad's in-launch fold; MI355X_MICROARCH.md, "Valid forms").
-        const int c_end = (int)blockIdx.x + 8 * (1 + (int)((item >> 28) & 7));
-        for (int c2 = blockIdx.x + 8; c2 < c_end; c2 += 8) {  // the next workgroups of this XCD
-          if (threadIdx.x == 0) {
-            unsigned spins = 0, f;
-            while (((f = __hip_atomic_load((unsigned*)sk_ws + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 4) != (sk_seq & 0x0FFFFFFFu) &&
-                   spins < (1u << 20)) {
-              __builtin_amdgcn_s_sleep(8);
-              ++spins;
-            }
-            if (spins >= (1u << 20))  // cannot happen with a resident grid: flag it (hct_gemm_nt_flags_offset) instead of hanging the GPU
-              __hip_atomic_store((unsigned*)sk_ws + kSkErrWord, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // Same XCD (the rule, see the item set-up): the slab was written THROUGH this XCD's L2 and is read below by loads that
-            // bypass the vector L1 (sc1), so nothing has to be invalidated.  Another XCD: agent-scope acquire first -- it drops the
-            // L2's clean lines, the operand panels of all 32 CUs with them, which is why it is not done unconditionally.
-            if ((f & 15) != xcc_id()) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          }
-          __syncthreads();
-          const __amdgpu_buffer_rsrc_t rs =
-              __builtin_amdgcn_make_buffer_rsrc(sk_ws + kSkHeadBytes + (size_t)c2 * kSkSlabBytes, 0, (uint32_t)kSkSlabBytes, 0x00020000);
-          int ln = lane;
-          asm volatile("" : "+v"(ln));
-          const uint32_t off0 = (uint32_t)(wave * 32768 + ln * 16);
-#pragma unroll
-          for (int i = 0; i < 4; i += 2) {  // 16 loads (16 KiB per wave) in flight: the fragment registers are dead here
-            f32x4 v[2][8];
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-              for (int j = 0; j < 8; ++j)
-                v[u][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off0 + (uint32_t)(((i + u) * 8 + j) * 1024), 0, 16));
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-              for (int j = 0; j < 8; ++j) acc[i + u][j] += v[u][j];
-          }
-        }
-      }
-      // generic: ring buffers 3 and 4 (8 KiB per wave), refilled only after the next tile's first barrier; specialised: buffer 4
-      unsigned char* patch = kTwoPairs ? smem + 4 * 32768 + wave * 4096 : smem + 3 * 32768 + wave * 8192;
-      if (MODE == EPI_GENERIC) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) epilogue_tile16x128(e, patch, lane, cm0 + wm * 64 + i * 16, cn0 + wn * 128, M, N, acc[i]);
-      } else {
-        TileBufs tb;
-        const int csz = (MODE == EPI_RES_F32) ? 4 : 2;
-        tb.c = tile_rsrc(e.C, e.ldc, csz, cm0, cn0, M, N);
-        tb.res = tile_rsrc(MODE == EPI_RES_F32 ? (const void*)e.residual : nullptr, e.ldr, 4, cm0, cn0, M, N);
-        tb.aux = tile_rsrc((MODE == EPI_GELU_BF16 || MODE == EPI_DGELU_BF16 || MODE == EPI_DGELU_CS) ? e.aux : nullptr, e.ldaux, 2, cm0, cn0, M, N);
-        f32x4 cs[2][2] = {{f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}};
-        epilogue_wave64x128_h<MODE, (MODE == EPI_RES_F32 ? HCT_RES_POLICY : kNT)>(e, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bh, cs);
-        if (MODE == EPI_DGELU_CS) {  // lanes l, l+8, ..., l+56 hold 8 different rows of the same 8 columns
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                cs[h][u][q] += __shfl_xor(cs[h][u][q], 8, 64);
-                cs[h][u][q] += __shfl_xor(cs[h][u][q], 16, 64);
-                cs[h][u][q] += __shfl_xor(cs[h][u][q], 32, 64);
-              }
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int n = cn0 + wn * 128 + h * 64 + (lane & 7) * 8;
-            if (lane < 8 && n < N) {
-              float* dst = colsum_out + ((int64_t)((cm0 >> 8) * 4 + wm)) * N + n;
-              Vec4<float>::store(dst, cs[h][0]);
-              Vec4<float>::store(dst + 4, cs[h][1]);
-            }
-          }
-        }
-      }
-    }
-    HCT_STAMP(3);
-#ifdef HCT_STAMPS
-    ++tile_i;
-#endif
-    if (!more) break;
-  }
-#ifdef HCT_STAMPS
-  if (g_stamp_ptr && wave == 0 && blockIdx.x * 64 + lane < g_stamp_words) g_stamp_ptr[blockIdx.x * 64 + lane] = stamps;
-#endif
-}
-
-// ---- NT, two workgroups per CU: 256x128 tile, 4 waves x (64x128), 3-stage ring (72 KiB) -----------------------------
-// Same pipeline and epilogue as the 256x256 kernel, but sized so that TWO workgroups are resident on a CU (2 waves per
-// SIMD in total): while one workgroup drains its tile (LDS patch -> buffer stores; vmcnt is in-order, so a wave cannot
-// run ahead of its own stores) the other one keeps the matrix pipes busy.  Pays 1.5x the LDS-DMA bytes per FLOP of the
-// 256x256 tile, so it is used for the short-K, wide-output GEMMs whose epilogue dominates (measured crossover in
-// hct_gemm).  Ring of 3: stage t+3 reuses the buffer of stage t at the mid-stage barrier, after lgkmcnt(0).
-template <int MODE>
-__global__ void __launch_bounds__(256, 2) gemm_bf16_nt_w4_kernel(int M, int N, int K, const bf16* __restrict__ A, int64_t lda,
-                                                                 const bf16* __restrict__ B, int64_t ldb, Epilogue e, int ntiles,
-                                                                 int stagger) {
-  constexpr int kStage = 24576;  // A 256 x 64 B | B 128 x 64 B
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * kStage];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ntm = (M + 255) >> 8, ntn = (N + 127) >> 7;
-
-  uint32_t voa[4], vob[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 16 + (lane >> 2);
-    voa[i] = (uint32_t)(row * lda * 2 + (((lane & 3) ^ swz64(row)) << 4));
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (wave * 2 + i) * 16 + (lane >> 2);
-    vob[i] = (uint32_t)(row * ldb * 2 + (((lane & 3) ^ swz64(row)) << 4));
-  }
-  const int wm = wave;
-  const int frow = lane & 15, fchk = lane >> 4;
-  const int foff = frow * 64 + ((fchk ^ swz64(frow)) << 4);
-  const int nk = K >> 5;
-
-  __amdgpu_buffer_rsrc_t ra, rb;
-  int m0 = 0, n0 = 0;
-  auto set_tile = [&](int vb) {
-    const int nwg = ntm * ntn;
-    const int xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
-    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
-    const int tm = id / ntn, tn = id - tm * ntn;
-    m0 = tm << 8;
-    n0 = tn << 7;
-    ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)m0 * lda), 0, clamp_records(((int64_t)(M - m0 - 1) * lda + K) * 2), 0x00020000);
-    rb = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (int64_t)n0 * ldb), 0, clamp_records(((int64_t)(N - n0 - 1) * ldb + K) * 2), 0x00020000);
-  };
-  auto bufof = [&](int t) -> unsigned char* { return smem + (t % 3) * kStage; };
-  auto stage = [&](int t) {
-    unsigned char* base = bufof(t);
-    const uint32_t kb = (uint32_t)t * 64;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + (wave * 4 + i) * 1024), 16, voa[i], kb, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + 16384 + (wave * 2 + i) * 1024), 16, vob[i], kb, 0, 0);
-  };
-  f32x4 acc[4][8];
-  bf16x8 b_lo[4], b_hi[4], a0[4], a1[4];
-  auto rd_a = [&](int t, bf16x8* af) {
-    const unsigned char* sa = bufof(t) + wm * 4096 + foff;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 1024);
-  };
-  auto rd_b = [&](int t, int half, bf16x8* bq) {
-    const unsigned char* sb = bufof(t) + 16384 + half * 4096 + foff;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const bf16x8*>(sb + j * 1024);
-  };
-  auto mma = [&](int half, const bf16x8* af, const bf16x8* bq) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][half * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[i][half * 4 + j], 0, 0, 0);
-  };
-  // own DMA retired (leaving `later` younger stages = 6 loads each in flight), every fragment read issued so far has
-  // returned (so the buffer of the current stage may be refilled right after), then barrier
-  auto land = [&](int later) {
-    if (later >= 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
-
-  // the two workgroups of a CU do identical work: start the second half of the grid half a tile late so that one's
-  // epilogue falls into the other's main loop instead of both alternating in lockstep
-  if (stagger > 0 && (int)blockIdx.x >= (int)(gridDim.x >> 1))
-    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
-  for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
-    set_tile(vb);
-    stage(0);
-    stage(1);
-    stage(2);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    land(2);
-    rd_a(0, a0);
-    rd_b(0, 0, b_lo);
-    int t = 0;
-    for (; t + 4 < nk; t += 2) {
-      rd_b(t, 1, b_hi);
-      mma(0, a0, b_lo);
-      land(1);
-      stage(t + 3);
-      rd_a(t + 1, a1);
-      rd_b(t + 1, 0, b_lo);
-      mma(1, a0, b_hi);
-      rd_b(t + 1, 1, b_hi);
-      mma(0, a1, b_lo);
-      land(1);
-      stage(t + 4);
-      rd_a(t + 2, a0);
-      rd_b(t + 2, 0, b_lo);
-      mma(1, a1, b_hi);
-    }
-    rd_b(t, 1, b_hi);
-    mma(0, a0, b_lo);
-    land(1);
-    stage(t + 3);
-    rd_a(t + 1, a1);
-    rd_b(t + 1, 0, b_lo);
-    mma(1, a0, b_hi);
-    rd_b(t + 1, 1, b_hi);
-    mma(0, a1, b_lo);
-    land(1);
-    rd_a(t + 2, a0);
-    rd_b(t + 2, 0, b_lo);
-    mma(1, a1, b_hi);
-    rd_b(t + 2, 1, b_hi);
-    mma(0, a0, b_lo);
-    land(0);
-    rd_a(t + 3, a1);
-    rd_b(t + 3, 0, b_lo);
-    mma(1, a0, b_hi);
-    rd_b(t + 3, 1, b_hi);
-    mma(0, a1, b_lo);
-    mma(1, a1, b_hi);
-
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // ring free: reuse it for the epilogue patches (4 waves x 8 KiB)
-    {
-      unsigned char* patch = smem + wave * 8192;
-      TileBufs tb;
-      if (MODE != EPI_GENERIC) {
-        const int csz = (MODE == EPI_RES_F32 || MODE == EPI_PLAIN_F32) ? 4 : 2;
-        tb.c = tile_rsrc(e.C, e.ldc, csz, m0, n0, M, N);
-        tb.res = tile_rsrc(MODE == EPI_RES_F32 ? (const void*)e.residual : nullptr, e.ldr, 4, m0, n0, M, N);
-        tb.aux = tile_rsrc((MODE == EPI_GELU_BF16 || MODE == EPI_DGELU_BF16) ? e.aux : nullptr, e.ldaux, 2, m0, n0, M, N);
-      }
-      if (MODE == EPI_GENERIC) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) epilogue_tile16x128(e, patch, lane, m0 + wm * 64 + i * 16, n0, M, N, acc[i]);
-      } else {
-        TileBias bv = tile_bias<MODE>(e, n0, 0, lane, N);
-        f32x4 cs0 = {0, 0, 0, 0}, cs1 = {0, 0, 0, 0};
-        epilogue_wave64x128_m<MODE>(e, tb, patch, lane, m0, n0, wm * 64, 0, M, N, acc, bv, cs0, cs1);
-      }
-    }
-    __syncthreads();  // patches dead before the next tile's DMA overwrites the ring
-  }
-}
-
-// ---- TN, 256x256 tile: C[M,N] (+)= A[R,M]^T . B[R,N]  (wgrad), same ring / pipeline / epilogue as the NT kernel ------
-// LDS stage = A[32 r][256 m] | B[32 r][256 n] bf16 (512-B rows = whole lines per DMA piece of 2 rows); the 32-B block nb of
-// row r sits at block  nb ^ f(r),  f(r) = (r&3) | ((r>>3)&1)<<2, which makes the ds_read_b64_tr_b16 fragment reads
-// conflict-free.  Work item = (split over R, tile); every split reduces r_chunk rows (zero-filled past R) and writes an
-// fp32 partial (or the final C when splits == 1); a fold kernel adds the partials in fixed order.
-__global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, int R, int r_chunk, const bf16* __restrict__ A,
-                                                                 int64_t lda, const bf16* __restrict__ B, int64_t ldb,
-                                                                 float* __restrict__ slab, Epilogue e, int ntiles, int splits,
-                                                                 unsigned int* __restrict__ counters) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[163840];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ntm = (M + 255) >> 8, ntn = (N + 255) >> 8, nmn = ntm * ntn;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nk = r_chunk >> 5;
-  const uint32_t OOB = 0xFFFFFFF0u;
-
-  // staging: 1 KiB piece = 2 reduction rows x 512 B; wave w moves pieces 2w, 2w+1 of A and of B each stage
-  uint32_t voa[2], vob[2];
-  // The operand stream of this kernel is issued as INLINE-ASM LDS-DMA.  With the builtin, hipcc (ROCm 7.2) inserts
-  // s_waitcnt vmcnt(0) between a stage's DMA issue and the ds_read_b64_tr_b16 fragment reads (it treats the transposed
-  // read as aliasing every pending LDS-DMA), which drains the whole ring every stage: the kernel then runs at one DMA
-  // round trip per 32-row stage (~1.4 us instead of ~0.45).  Ordering is enforced by the counted vmcnt waits + barriers
-  // below; compiler-generated vmcnt waits for its own loads/stores only become more conservative.
-  i32x4 ra, rb;  // buffer descriptors {base_lo, base_hi, num_records, flags} in SGPRs
-  const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
-  int m0 = 0, n0 = 0, sp = 0;
-  auto set_tile = [&](int vb) {
-    const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7;
-    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
-    sp = id / nmn;
-    const int rem = id - sp * nmn;
-    const int tm = rem / ntn, tn = rem - tm * ntn;
-    m0 = tm << 8;
-    n0 = tn << 8;
-    const int rbeg = sp * r_chunk;
-    const int rows = min(R, rbeg + r_chunk) - rbeg;
-    const bf16* Ab = A + (int64_t)rbeg * lda + m0;
-    const bf16* Bb = B + (int64_t)rbeg * ldb + n0;
-    ra = make_srd(Ab, clamp_records(((int64_t)(rows - 1) * lda + (M - m0)) * 2));
-    rb = make_srd(Bb, clamp_records(((int64_t)(rows - 1) * ldb + (N - n0)) * 2));
-    // lane offsets recomputed per tile from an opaque lane id (a dozen VALU): as tile-invariant values hipcc kept them in
-    // VGPRs across the main loop, spilled them, and reloaded them here one by one with s_waitcnt vmcnt(0)
-    int l = lane;
-    asm volatile("" : "+v"(l));
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int srow = (wave * 2 + i) * 2 + (l >> 5);
-      const int slot = l & 31;
-      const int f = (srow & 3) | (((srow >> 3) & 1) << 2);
-      const int scol = ((((slot >> 1) ^ f) << 1) | (slot & 1)) * 8;
-      voa[i] = (m0 + scol < M) ? (uint32_t)((srow * lda + scol) * 2) : OOB;
-      vob[i] = (n0 + scol < N) ? (uint32_t)((srow * ldb + scol) * 2) : OOB;
-    }
-  };
-  auto stage = [&](int t) {
-    const uint32_t base = lds0 + (t & 3) * 32768;
-    uint32_t ka = (uint32_t)(t * 32 * lda * 2), kb = (uint32_t)(t * 32 * ldb * 2);
-    // opaque per call: otherwise hipcc pre-adds the stage offsets of the three prefetch stages into 12 long-lived VGPRs,
-    // spills them and reloads each with s_waitcnt vmcnt(0) between the prefetch DMAs
-    asm volatile("" : "+s"(ka), "+s"(kb));
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = wave * 2 + i;
-      // NOTE: the reduction-row offset must stay in voffset here (rows past the split's end are zero-filled by the
-      // descriptor's range check, which does not see soffset)
-      dma16(ra, base + c * 1024, voa[i] == OOB ? OOB : voa[i] + ka);
-      dma16(rb, base + 16384 + c * 1024, vob[i] == OOB ? OOB : vob[i] + kb);
-    }
-  };
-  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
-  const int ff = qq | ((g & 1) << 2);
-  const int rowb = (8 * g + qq) * 512 + pp * 8;
-  auto frag = [&](const unsigned char* tile, int nb) -> bf16x8 {
-    const unsigned char* pa = tile + rowb + ((nb ^ ff) << 5);
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * 512));
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
-  };
-  f32x4 acc[4][8];
-  bf16x8 b_lo[4], b_hi[4], a0[4], a1[4];
-  auto rd_a = [&](int t, bf16x8* af) {
-    const unsigned char* sa = smem + (t & 3) * 32768;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = frag(sa, wm * 4 + i);
-  };
-  auto rd_b = [&](int t, int half, bf16x8* bq) {
-    const unsigned char* sb = smem + (t & 3) * 32768 + 16384;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bq[j] = frag(sb, wn * 8 + half * 4 + j);
-  };
-  auto mma = [&](int half, const bf16x8* af, const bf16x8* bq) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][half * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[i][half * 4 + j], 0, 0, 0);
-  };
-  // half of a half-stage (rows 32*part .. 32*part+31 of the wave tile): lets the 16 transposed reads of the next stage be
-  // issued as 8 + 8 around it, so no wait ever needs more than the 15 outstanding LDS ops lgkmcnt can express
-  auto mma_part = [&](int half, int part, const bf16x8* af, const bf16x8* bq) {
-#pragma unroll
-    for (int i = 2 * part; i < 2 * part + 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][half * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[i][half * 4 + j], 0, 0, 0);
-  };
-  auto land = [&](int later) {
-    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
-
-  int vb = blockIdx.x;
-  set_tile(vb);
-  stage(0);
-  stage(1);
-  stage(2);
-  while (true) {
-    const int cm0 = m0, cn0 = n0, csp = sp;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    land(2);
-    rd_a(0, a0);
-    rd_b(0, 0, b_lo);
-    int t = 0;
-    for (; t + 4 < nk; t += 2) {
-      rd_b(t, 1, b_hi);
-      mma(0, a0, b_lo);
-      land(1);
-      stage(t + 3);
-      rd_a(t + 1, a1);
-      mma_part(1, 0, a0, b_hi);
-      rd_b(t + 1, 0, b_lo);
-      mma_part(1, 1, a0, b_hi);
-      rd_b(t + 1, 1, b_hi);
-      mma(0, a1, b_lo);
-      land(1);
-      stage(t + 4);
-      rd_a(t + 2, a0);
-      mma_part(1, 0, a1, b_hi);
-      rd_b(t + 2, 0, b_lo);
-      mma_part(1, 1, a1, b_hi);
-    }
-    rd_b(t, 1, b_hi);
-    mma(0, a0, b_lo);
-    land(1);
-    stage(t + 3);
-    rd_a(t + 1, a1);
-    mma_part(1, 0, a0, b_hi);
-    rd_b(t + 1, 0, b_lo);
-    mma_part(1, 1, a0, b_hi);
-    rd_b(t + 1, 1, b_hi);
-    mma(0, a1, b_lo);
-    land(1);
-    rd_a(t + 2, a0);
-    mma_part(1, 0, a1, b_hi);
-    rd_b(t + 2, 0, b_lo);
-    mma_part(1, 1, a1, b_hi);
-    rd_b(t + 2, 1, b_hi);
-    mma(0, a0, b_lo);
-    land(0);
-    rd_a(t + 3, a1);
-    mma_part(1, 0, a0, b_hi);
-    rd_b(t + 3, 0, b_lo);
-    mma_part(1, 1, a0, b_hi);
-    rd_b(t + 3, 1, b_hi);
-    mma(0, a1, b_lo);
-    mma(1, a1, b_hi);
-
-    __builtin_amdgcn_s_barrier();
-    TileBias bv = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-    if (!slab) bv = tile_bias<EPI_PLAIN_F32>(e, cn0, wn * 128, lane, N);
-    vb += gridDim.x;
-    const bool more = vb < ntiles;
-    if (more) {
-      set_tile(vb);
-      stage(0);
-      stage(1);
-      stage(2);
-    }
-    {
-      unsigned char* patch = smem + 3 * 32768 + wave * 8192;
-      Epilogue eo = e;
-      if (slab) {  // raw fp32 partial of this split; the fold kernel applies alpha and the output dtype
-        eo.bias = nullptr; eo.alpha = 1.0f;
-        eo.C = slab + (int64_t)csp * M * N; eo.ldc = N;
-      }
-      TileBufs tb;
-      tb.c = tile_rsrc(eo.C, eo.ldc, 4, cm0, cn0, M, N);
-      tb.res = tile_rsrc(nullptr, 0, 4, cm0, cn0, M, N);
-      tb.aux = tb.res;
-      f32x4 cs0 = {0, 0, 0, 0}, cs1 = {0, 0, 0, 0};
-      // partial slabs leave write-through (sc1): they are handed to other workgroups below, and a write-through store needs
-      // no release fence (publishing 256 KB of plain stores with buffer_wbl2 costs several us per workgroup)
-      // (with the separate fold kernel -- the default -- the kernel boundary publishes them: policy HCT_SLAB_POLICY)
-      if (slab && counters) epilogue_wave64x128_m<EPI_PLAIN_F32, 16>(eo, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv, cs0, cs1);
-      else if (slab) epilogue_wave64x128_m<EPI_PLAIN_F32, HCT_SLAB_POLICY>(eo, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv, cs0, cs1);
-      else epilogue_wave64x128_m<EPI_PLAIN_F32>(eo, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bv, cs0, cs1);
-    }
-    if (slab && counters) {  // publish this split's partial: every wave's stores have left, then ONE arrival on the tile's counter
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_fetch_add(counters + (cm0 >> 8) * ntn + (cn0 >> 8), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (!more) break;
-  }
-  if (!slab || !counters) return;
-  // ---- split fold inside the launch ------------------------------------------------------------------------------------
-  // All splits of a tile are co-resident (grid <= #CUs, one 160-KiB workgroup per CU) or queued behind workgroups that never
-  // wait before publishing, so waiting for the tile's arrival count cannot deadlock: a workgroup publishes ALL its items
-  // first and only then takes up its fold duties.  Every one of the tile's `splits` workgroups then sums 1/splits of the
-  // tile's rows over the slabs in split order 0, 1, 2, ... (fixed order: bit-reproducible whatever the arrival order) and
-  // writes the final fp32 C.  Slab bytes were stored write-through (sc1) and drained before the arrival; the consumer
-  // polls relaxed, then ONE agent-scope acquire drops its L1 lines before the plain loads: placement-independent
-  // (MI355X_MICROARCH.md, "Valid forms").
-  unsigned int* const done = counters + 64;
-  for (int vb2 = blockIdx.x; vb2 < ntiles; vb2 += gridDim.x) {
-    const int xcd = vb2 & 7, q = ntiles >> 3, r = ntiles & 7;
-    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb2 >> 3);
-    const int fsp = id / nmn, tile = id - fsp * nmn;
-    const int tm = tile / ntn, tn = tile - tm * ntn;
-    int& s_timeout = *reinterpret_cast<int*>(smem);  // the ring is idle now (every wave is past the publish barrier)
-    if (threadIdx.x == 0) {
-      unsigned spins = 0;
-      while (__hip_atomic_load(counters + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)splits && spins < (1u << 20)) {
-        __builtin_amdgcn_s_sleep(8);
-        ++spins;
-      }
-      s_timeout = spins >= (1u << 20);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's stale L1 lines of the slabs
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    if (s_timeout) {  // a split never arrived (cannot happen with a resident grid): flag it instead of hanging the GPU
-      if (threadIdx.x == 0) __hip_atomic_store(counters + 128, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      continue;
-    }
-    // this workgroup's share of the tile: rows [r0, r1)
-    const int r0 = (fsp * 256) / splits, r1 = ((fsp + 1) * 256) / splits;
-    const int cols4 = 64;  // 256 columns as float4
-    const float* tile_base = slab + ((int64_t)tm * 256) * N + tn * 256;
-    const int64_t zstride = (int64_t)M * N;
-    float* Cf = (float*)e.C;
-    // 8 outputs x 4 splits = 32 independent 16-B loads in flight per thread: the slabs come from the Infinity Cache / another
-    // XCD's L2 at ~2 us per round trip, so a thread that waits for 4 loads at a time spends 8 round trips on its share
-    const int nelem = (r1 - r0) * cols4;
-    for (int g0 = 0; g0 < nelem; g0 += 512 * 8) {
-      const float* src[8];
-      float* dst[8];
-      f32x4 sum[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = g0 + k * 512 + (int)threadIdx.x;
-        const int rr = r0 + i / cols4, c4 = (i % cols4) * 4;
-        const int m = tm * 256 + rr, n = tn * 256 + c4;
-        const bool ok = i < nelem && m < M && n < N;
-        src[k] = ok ? tile_base + (int64_t)rr * N + c4 : nullptr;
-        dst[k] = ok ? Cf + (int64_t)m * e.ldc + n : nullptr;
-        sum[k] = f32x4{0, 0, 0, 0};
-      }
-      for (int z = 0; z < splits; z += 4) {
-        f32x4 v[4][8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int k = 0; k < 8; ++k)
-            v[u][k] = (src[k] && z + u < splits) ? *reinterpret_cast<const f32x4*>(src[k] + (int64_t)(z + u) * zstride) : f32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int u = 0; u < 4; ++u)  // split order 0, 1, 2, ... per output (adding the zero of an absent split changes nothing)
-#pragma unroll
-          for (int k = 0; k < 8; ++k) sum[k] += v[u][k];
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (dst[k]) *reinterpret_cast<f32x4*>(dst[k]) = sum[k] * e.alpha;
-    }
-    // last one out re-arms the tile's counters for the next launch on this workspace
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned prev = __hip_atomic_fetch_add(done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (prev == (unsigned)splits - 1) {
-        __hip_atomic_store(done + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-}
-
-// ---- TN, GROUPED: many weight-gradient products in ONE persistent launch, no split over R --------------------------------
-// The weight gradients are not on the backward's dependency chain (only the optimizer reads them), so the model driver collects the
-// wgrads of several blocks and runs them here together.  With enough output tiles to fill the chip there is no need to split the
-// reduction: no fp32 partial slabs (65 MB per product before), no fold launch, one prologue / epilogue per 256x256 tile of the
-// FULL reduction instead of one per split, two launches per step instead of 166.
-//   tiles    : listed job-major, tile t of a job = (t / ntn, t % ntn); T tiles in all, G = grid = #CUs.
-//   rounds   : the first F = T / G rounds are whole tiles; workgroup c takes tile r * G + q(c) in round r, q(c) = (c & 7) * G/8 +
-//              (c >> 3): the 32 workgroups of an XCD (dealt round-robin) sweep the reduction rows of 32 consecutive tiles -- mostly
-//              ONE product -- together, so its A / B row panels are fetched once per XCD (as the splits of one product were before).
-//   remainder: the last T - F * G tiles are shared out by reduction range ("stream-K"): their stages (32 rows each, a multiple of
-//              4 per tile) form one sequence of S stages, cut into W contiguous ranges at multiples of 4; a range is split at tile
-//              boundaries into at most one FOLLOWER piece (starts inside a tile: raw accumulators to slab q, then flag q) and
-//              whole / OWNER pieces (start a tile; an owner adds the slabs of the workgroups that continue its tile, in order
-//              q+1, q+2, ... -- fixed order, bit-reproducible -- and runs the epilogue).  The follower piece is the first thing a
-//              workgroup does in the remainder phase and never waits: no cycles.  A bounded spin poisons the tile with NaN (the
-//              engine's finite-loss check then stops the run) instead of hanging should the grid not be resident.
-struct TnJob {                 // 80 bytes, device copy written by tn_group_table_kernel
-  const bf16* A; const bf16* B; float* C;
-  int M, N, R, lda, ldb, ldc;
-  int tile0, ntiles, ntn, nk;  // first tile id, tiles, column tiles, stages per tile (R / 32 rounded up to a multiple of 4)
-  float alpha; int pad[3];
-};
-constexpr int kTnGroupChunk = 32;  // jobs per table-writer launch (kernel arguments stay under 4 KiB)
-struct TnJobChunk { TnJob j[kTnGroupChunk]; };
-__global__ void tn_group_table_kernel(TnJob* __restrict__ dst, TnJobChunk c, int first, int n) {
-  const int i = threadIdx.x;
-  if (i < n) dst[first + i] = c.j[i];
-}
-
-__global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob* __restrict__ jobs, int njobs, int T, int F, int S_rem,
-                                                                    int W, unsigned char* __restrict__ sk_ws, unsigned sk_seq) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[163840];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const uint32_t OOB = 0xFFFFFFF0u;
-  const int G = gridDim.x;
-  const int q = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);  // XCD-contiguous index
-
-  uint32_t voa[2], vob[2];
-  i32x4 ra, rb;
-  const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
-  // ---- item = (job, tile, first stage, stages, kind) ----------------------------------------------------------------------
-  int jc = 0;                       // job cursor: tile ids only grow along a workgroup's walk
-  int round = 0;                    // whole-tile rounds done
-  int rp = -1, rp1 = 0;             // remainder phase: position / end of this workgroup's stage range (-1: not entered yet)
-  int rg = 0, rbase = 0;            // ... tile id and stage position of the first remainder tile of job jc that is not passed yet
-  // the item being SET UP (next to compute):
-  int M = 0, N = 0, lda = 0, ldb = 0, ldc = 0, m0 = 0, n0 = 0, ns = 0, kind = 0, nf = 0;
-  float alpha = 1.f;
-  float* Cp = nullptr;
-  auto job_tile_end = [&](int j) { return jobs[j].tile0 + jobs[j].ntiles; };
-  auto set_item = [&](int j, int t, int s0, int nst, int knd, int nfol) {  // tile t of job j, stages [s0, s0 + nst)
-    const TnJob jb = jobs[j];
-    M = jb.M; N = jb.N; lda = jb.lda; ldb = jb.ldb; ldc = jb.ldc; alpha = jb.alpha; Cp = jb.C;
-    const int tm = t / jb.ntn, tn = t - tm * jb.ntn;
-    m0 = tm << 8;
-    n0 = tn << 8;
-    ns = nst; kind = knd; nf = nfol;
-    const int rbeg = s0 * 32;
-    const int rows = (jb.R < rbeg + nst * 32 ? jb.R : rbeg + nst * 32) - rbeg;  // (>= 1: a piece never starts past the last row's stage)
-    const bf16* Ab = jb.A + (int64_t)rbeg * lda + m0;
-    const bf16* Bb = jb.B + (int64_t)rbeg * ldb + n0;
-    ra = make_srd(Ab, clamp_records(rows > 0 ? ((int64_t)(rows - 1) * lda + (M - m0)) * 2 : 0));
-    rb = make_srd(Bb, clamp_records(rows > 0 ? ((int64_t)(rows - 1) * ldb + (N - n0)) * 2 : 0));
-    int l = lane;
-    asm volatile("" : "+v"(l));  // lane offsets recomputed per item (see gemm_bf16_tn256_kernel)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int srow = (wave * 2 + i) * 2 + (l >> 5);
-      const int slot = l & 31;
-      const int f = (srow & 3) | (((srow >> 3) & 1) << 2);
-      const int scol = ((((slot >> 1) ^ f) << 1) | (slot & 1)) * 8;
-      voa[i] = (m0 + scol < M) ? (uint32_t)((srow * lda + scol) * 2) : OOB;
-      vob[i] = (n0 + scol < N) ? (uint32_t)((srow * ldb + scol) * 2) : OOB;
-    }
-  };
-  auto next_item = [&]() -> bool {
     if (round < F) {  // whole tile of round `round`
       const int g = round * G + q;
       ++round;
@@ -2705,7 +1960,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob*
       stage(1);
       stage(2);
     }
-    if (ckind == 1) {
+    if (__builtin_expect(ckind == 1, 0)) {
       // FOLLOWER piece: raw accumulators in register order (1 KiB per store instruction), write-through, then ONE flag
       const __amdgpu_buffer_rsrc_t rs =
           __builtin_amdgcn_make_buffer_rsrc(sk_ws + kSkHeadBytes + (size_t)q * kSkSlabBytes, 0, (uint32_t)kSkSlabBytes, 0x00020000);
@@ -2724,7 +1979,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob*
       if (more) {  // the drain above also waited for the next item's first stages; nothing else to restore
       }
     } else {
-      if (ckind == 2) {
+      if (__builtin_expect(ckind == 2, 0)) {
         // OWNER: add the partials of the workgroups that continued this tile, order q+1, q+2, ... (protocol of the NT stream-K)
         int& s_bad = *reinterpret_cast<int*>(smem + 3 * 32768 + 65536 - 16);  // (last bytes of the patch area: not written before the epilogue)
         for (int c2 = q + 1; c2 <= q + cnf; ++c2) {
@@ -2747,17 +2002,13 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob*
           asm volatile("" : "+v"(ln));
           const uint32_t off0 = (uint32_t)(wave * 32768 + ln * 16);
 #pragma unroll
-          for (int i = 0; i < 4; i += 2) {
-            f32x4 v[2][8];
+          for (int i = 0; i < 4; ++i) {  // 8 loads (8 KiB per wave) in flight: once per workgroup and launch, registers matter more here
+            f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int j = 0; j < 8; ++j)
+              v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off0 + (uint32_t)((i * 8 + j) * 1024), 0, 16));
 #pragma unroll
-              for (int j = 0; j < 8; ++j)
-                v[u][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off0 + (uint32_t)(((i + u) * 8 + j) * 1024), 0, 16));
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-              for (int j = 0; j < 8; ++j) acc[i + u][j] += v[u][j];
+            for (int j = 0; j < 8; ++j) acc[i][j] += v[j];
           }
           if (bad) {  // a partial never arrived: poison the tile (the finite-loss check of the engine stops the run)
             const float nanv = __builtin_nanf("");
@@ -3084,13 +2335,20 @@ size_t hct_gemm_nt_flags_offset(size_t workspace_bytes) {
 // ---- grouped wgrad (gemm_bf16_tn_group_kernel) --------------------------------------------------------------------------
 static size_t tn_group_table_bytes(int n) { return align_up((size_t)n * sizeof(TnJob), 4096); }
 
+}  // extern "C"
+namespace hct {
+bool tn_group_ok(const hct_gemm_args* a) {  // (quiet form for the model driver: falls back to the split-K launch otherwise)
+  return a->transA == 1 && a->transB == 0 && a->a_dtype == HCT_BF16 && a->b_dtype == HCT_BF16 && a->c_dtype == HCT_F32 && !a->bias &&
+         !a->residual && a->act == HCT_ACT_NONE && !a->aux && !a->C2 && !a->colsum_out && a->M > 0 && a->N > 0 && a->K > 0 && a->M % 16 == 0 &&
+         a->N % 16 == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 4 == 0 && aligned_to(a->A, 16) && aligned_to(a->B, 16) &&
+         aligned_to(a->C, 16) && a->A && a->B && a->C && a->ldc * 256 < (1ll << 28) && (int64_t)a->K * a->lda * 2 < 0xFFFFFFF0ll &&
+         (int64_t)a->K * a->ldb * 2 < 0xFFFFFFF0ll && a->lda < (1 << 24) && a->ldb < (1 << 24);
+}
+}  // namespace hct
+extern "C" {
+
 static int tn_group_check(const hct_gemm_args* a, int i) {
-  const bool ok = a->transA == 1 && a->transB == 0 && a->a_dtype == HCT_BF16 && a->b_dtype == HCT_BF16 && a->c_dtype == HCT_F32 && !a->bias &&
-                  !a->residual && a->act == HCT_ACT_NONE && !a->aux && !a->C2 && !a->colsum_out && a->M > 0 && a->N > 0 && a->K > 0 &&
-                  a->M % 16 == 0 && a->N % 16 == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 4 == 0 && aligned_to(a->A, 16) &&
-                  aligned_to(a->B, 16) && aligned_to(a->C, 16) && a->A && a->B && a->C && a->ldc * 256 < (1ll << 28) &&
-                  (int64_t)a->K * a->lda * 2 < 0xFFFFFFF0ll && (int64_t)a->K * a->ldb * 2 < 0xFFFFFFF0ll && a->lda < (1 << 24) && a->ldb < (1 << 24);
-  if (!ok) {
+  if (!hct::tn_group_ok(a)) {
     set_error("hct_gemm_tn_group: job %d is not a plain bf16 weight-gradient product (transA = 1, transB = 0, fp32 C, no epilogue extras, "
               "M / N multiples of 16, 16-byte aligned operands, reduction span under 4 GiB)", i);
     return HCT_E_BADARG;

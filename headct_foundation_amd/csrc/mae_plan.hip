@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include "common.h"
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -28,6 +29,11 @@ struct BlockA {  // byte offsets into the workspace
   size_t x1, mean1, rstd1, qkv, o, lse, h_mid, x2, mean2, rstd2, u, g;
 };
 struct Act { size_t off; int64_t rows, cols; int dtype; };
+// gradient operands of one block's four weight gradients (compute dtype): gradient wrt the block output [M,d], wrt the MLP's
+// pre-activation [M,m], wrt h_mid [M,d], wrt qkv [M,3d].  They stay untouched until the block's weight gradients have run (the
+// grouped launch, see flush_wgrads): a ring of sets per side.
+struct BlockG { size_t out, big, mid, qkv; };
+constexpr int kWgSlots = 12;  // grouped weight-gradient launches per backward, at most (each keeps a prepared job table)
 
 }  // namespace
 
@@ -67,6 +73,19 @@ struct hct_mae_plan {
   size_t s_dh, s_dh_shadow, s_dbig, s_dx, s_do, s_dqkv, s_small, s_small_bytes, s_gemm, s_gemm_bytes, s_nt_bytes = 0;
   size_t s_fold_a = 0, s_fold_b = 0, s_fold_bytes = 0, s_small2 = 0, s_small2_bytes = 0;  // partial buffers of the deferred folds (block_backward)
   std::map<std::string, Act> acts;
+  // Deferred weight gradients.  dW = dY^T . X feeds nothing in the backward (only the optimizer reads it), so the products are
+  // queued (linear_wgrad) and run together in one persistent grouped launch (hct_gemm_tn_group_*: whole tiles over the full
+  // reduction, no split partials, no fold launches) when the decoder's / the encoder's backward is through, or every
+  // `wg_blocks` block stages (data parallelism: the gradient buckets then become final earlier).
+  bool wg_defer = false;
+  int wg_blocks = 0;                           // flush after this many block stages (0: at the decoder / encoder boundaries only)
+  int wg_blocks_pending = 0, wg_slot = 0;
+  std::vector<BlockG> genc, gdec;              // rings of gradient-operand sets; block i uses set i % size
+  size_t a_de = 0, a_dtok = 0;                 // gradient operands of decoder_embed / the patch embedding
+  std::vector<hct_gemm_args> wg_pending;
+  std::vector<hct_gemm_args> wg_prepared[kWgSlots];
+  size_t s_wg[kWgSlots] = {0}, s_wg_bytes = 0;
+  int64_t final_off = 0;                       // every gradient element at or behind this offset is final (hct_mae_backward_final_offset)
   // bound buffers
   float* params_f32 = nullptr;
   float* grads = nullptr;
@@ -273,10 +292,15 @@ int linear_wgrad(hct_mae_plan* p, const void* dY, const void* X, int M, int N, i
   a.A = dY; a.a_dtype = p->dt; a.lda = N; a.transA = 1;
   a.B = X; a.b_dtype = p->dt; a.ldb = K; a.transB = 0;
   a.C = p->gf(w); a.c_dtype = HCT_F32; a.ldc = K;
-  a.workspace_armed = p->gemm_ws_armed ? 1 : 0;  // s_gemm is this plan's alone: its fold counters are reset by the first wgrad after a bind
-  int rc = hct_gemm(&a, p->ws + p->s_gemm, p->s_gemm_bytes, s);
-  p->gemm_ws_armed = rc == 0;
-  if (rc) return rc;
+  int rc = 0;
+  if (p->wg_defer && tn_group_ok(&a)) {
+    p->wg_pending.push_back(a);  // runs with the next grouped launch (flush_wgrads); dY and X stay untouched until then
+  } else {
+    a.workspace_armed = p->gemm_ws_armed ? 1 : 0;  // s_gemm is this plan's alone: its fold counters are reset by the first wgrad after a bind
+    rc = hct_gemm(&a, p->ws + p->s_gemm, p->s_gemm_bytes, s);
+    p->gemm_ws_armed = rc == 0;
+    if (rc) return rc;
+  }
   if (b >= 0) rc = hct_colsum(dY, p->dt, M, N, N, p->gf(b), p->ws + p->s_small2, p->s_small2_bytes, s);  // (s_small's head may hold a deferred fold's partials)
   return rc;
 }
@@ -294,6 +318,45 @@ size_t wgrad_ws(int dt, int M, int N, int K) {
     int _rc = (x);       \
     if (_rc) return _rc; \
   } while (0)
+
+// Run the queued weight gradients as one grouped launch.  Longest reductions first (stable): the whole-tile rounds are then
+// homogeneous and the shorter products (the compact decoder tail, decoder_pred) end up in the last round and the stream-K
+// remainder, which is balanced by reduction stages.  The job table of a slot (= the n-th flush of a backward) is rewritten only
+// when the jobs differ from the ones it was last prepared for (pointers and shapes are the same every step).
+int flush_wgrads(hct_mae_plan* p, hipStream_t s) {
+  p->wg_blocks_pending = 0;
+  if (p->wg_pending.empty()) return 0;
+  std::vector<hct_gemm_args>& jobs = p->wg_pending;
+  std::stable_sort(jobs.begin(), jobs.end(), [](const hct_gemm_args& x, const hct_gemm_args& y) { return x.K > y.K; });
+  const int slot = p->wg_slot < kWgSlots ? p->wg_slot : kWgSlots - 1;
+  ++p->wg_slot;
+  const int n = (int)jobs.size();
+  if (hct_gemm_tn_group_workspace_bytes(n) > p->s_wg_bytes) {
+    set_error("plan: %d queued weight gradients exceed the grouped launch's workspace", n);
+    return HCT_E_WORKSPACE;
+  }
+  std::vector<hct_gemm_args>& prep = p->wg_prepared[slot];
+  if (prep.size() != jobs.size() || memcmp(prep.data(), jobs.data(), jobs.size() * sizeof(hct_gemm_args)) != 0) {
+    RC(hct_gemm_tn_group_prepare(jobs.data(), n, p->ws + p->s_wg[slot], p->s_wg_bytes, s));
+    prep = jobs;
+  }
+  RC(hct_gemm_tn_group_run(jobs.data(), n, p->ws + p->s_wg[slot], p->s_wg_bytes, s));
+  jobs.clear();
+  return 0;
+}
+
+// end of backward stage `stage`: flush where the policy says so, then move the "final" watermark
+int end_stage(hct_mae_plan* p, int stage, bool block_stage, bool boundary, int ring, hipStream_t s) {
+  if (block_stage) ++p->wg_blocks_pending;
+  const bool last = stage + 1 == (int)p->stage_range.size();
+  // a ring of r gradient-operand sets allows at most r - 1 block stages between flushes (the r-th block would overwrite the
+  // output gradient that the oldest queued product still reads)
+  int limit = p->wg_blocks > 0 ? p->wg_blocks : (1 << 30);
+  if (ring > 0 && ring - 1 < limit) limit = ring - 1;
+  if (last || boundary || p->wg_blocks_pending >= limit) RC(flush_wgrads(p, s));
+  if (p->wg_pending.empty()) p->final_off = p->stage_range[stage].first;
+  return 0;
+}
 
 // The MLP's saved activation is gelu'(pre-activation), written by the fc1 epilogue from the unrounded value; the fc2 dgrad then
 // multiplies by it (HCT_ACT_GELU_D / HCT_ACT_MULAUX) instead of evaluating gelu' a second time from a bf16-rounded input.
@@ -324,16 +387,18 @@ bool defer_folds() {  // HCT_DEFER_FOLDS=0: every fold as a launch of its own (A
   return on;
 }
 
-int block_backward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const float* h_in, int B, int N, int d, int m,
-                   int heads, int prev_fc2_b, hipStream_t s) {
+int block_backward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const BlockG& bg, size_t dhs_in_off, const float* h_in, int B, int N,
+                   int d, int m, int heads, int prev_fc2_b, hipStream_t s) {
   const int M = B * N;
   unsigned char* ws = p->ws;
   float* dh = (float*)(ws + p->s_dh);
-  void* dhs = ws + p->s_dh_shadow;
-  void* dbig = ws + p->s_dbig;
+  void* dhs = ws + bg.out;        // gradient wrt the block output (written by the stage before)
+  void* dhs_mid = ws + bg.mid;    // ... wrt h_mid
+  void* dhs_in = ws + dhs_in_off; // ... wrt the block input = the next stage's `out`
+  void* dbig = ws + bg.big;
   void* dx = ws + p->s_dx;
   void* d_o = ws + p->s_do;
-  void* dqkv = ws + p->s_dqkv;
+  void* dqkv = ws + bg.qkv;
   // The three fixed-order folds of this block (fc1 bias column sums; ln2 and ln1 gamma / beta / column sums) are recorded and run as
   // ONE launch at the end (common.h, FoldSink): each keeps a partial buffer of its own until then -- s_small's head, s_fold_a,
   // s_fold_b -- and nothing else in between writes those.
@@ -352,16 +417,16 @@ int block_backward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const fl
   RC(linear_wgrad(p, dbig, ws + ba.x2, M, m, d, bp.fc1_w, -1, s));
   RC(linear_dgrad(p, dbig, M, m, bp.fc1_w, d, dx, HCT_ACT_NONE, nullptr, s));
   RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + ba.h_mid), (const float*)(ws + ba.mean2), (const float*)(ws + ba.rstd2),
-                       p->pf(bp.ln2_w), dh, M, d, dh, dhs, p->dt, p->gf(bp.ln2_w), p->gf(bp.ln2_b), p->gf(bp.proj_b), ws + p->s_fold_a,
+                       p->pf(bp.ln2_w), dh, M, d, dh, dhs_mid, p->dt, p->gf(bp.ln2_w), p->gf(bp.ln2_b), p->gf(bp.proj_b), ws + p->s_fold_a,
                        p->s_fold_bytes, s));
   // attention branch
-  RC(linear_wgrad(p, dhs, ws + ba.o, M, d, d, bp.proj_w, -1, s));
-  RC(linear_dgrad(p, dhs, M, d, bp.proj_w, d, d_o, HCT_ACT_NONE, nullptr, s));
+  RC(linear_wgrad(p, dhs_mid, ws + ba.o, M, d, d, bp.proj_w, -1, s));
+  RC(linear_dgrad(p, dhs_mid, M, d, bp.proj_w, d, d_o, HCT_ACT_NONE, nullptr, s));
   RC(hct_attention_bwd(ws + ba.qkv, ws + ba.o, d_o, (const float*)(ws + ba.lse), B, N, heads, d / heads, p->dt, dqkv, s));
   RC(linear_wgrad(p, dqkv, ws + ba.x1, M, 3 * d, d, bp.qkv_w, bp.qkv_b, s));
   RC(linear_dgrad(p, dqkv, M, 3 * d, bp.qkv_w, d, dx, HCT_ACT_NONE, nullptr, s));
   RC(hct_layernorm_bwd(dx, p->dt, h_in, (const float*)(ws + ba.mean1), (const float*)(ws + ba.rstd1), p->pf(bp.ln1_w), dh, M, d,
-                       dh, dhs, p->dt, p->gf(bp.ln1_w), p->gf(bp.ln1_b), prev_fc2_b >= 0 ? p->gf(prev_fc2_b) : nullptr, ws + p->s_fold_b,
+                       dh, dhs_in, p->dt, p->gf(bp.ln1_w), p->gf(bp.ln1_b), prev_fc2_b >= 0 ? p->gf(prev_fc2_b) : nullptr, ws + p->s_fold_b,
                        p->s_fold_bytes, s));
   return fold_flush(sink, s);
 }
@@ -387,16 +452,19 @@ int block_forward_tail(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, cons
 
 // Its backward.  in: s_dhc (fp32 [Mc,d]) + s_dh_shadow (compute dtype, compact rows) = gradient wrt the block's compact output.
 // out: s_dh / s_dh_shadow hold the gradient wrt the block input on ALL rows.
-int block_backward_tail(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const float* h_in, int prev_fc2_b, hipStream_t s) {
+int block_backward_tail(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const BlockG& bg, size_t dhs_in_off, const float* h_in,
+                        int prev_fc2_b, hipStream_t s) {
   const int B = p->B, N = p->Nd, d = p->Dd, m = p->Mlpd, heads = p->Hd, M = B * N, Mc = p->Mc;
   unsigned char* ws = p->ws;
   float* dh = (float*)(ws + p->s_dh);
   float* dhc = (float*)(ws + p->s_dhc);
-  void* dhs = ws + p->s_dh_shadow;
-  void* dbig = ws + p->s_dbig;
+  void* dhs = ws + bg.out;         // compact rows
+  void* dhs_mid = ws + bg.mid;     // compact rows
+  void* dhs_in = ws + dhs_in_off;  // all rows
+  void* dbig = ws + bg.big;
   void* dx = ws + p->s_dx;
   void* d_o = ws + p->s_do;
-  void* dqkv = ws + p->s_dqkv;
+  void* dqkv = ws + bg.qkv;
   const int32_t* inv = (const int32_t*)(ws + p->a_tail_inv);
   FoldSink sink;
   struct SinkScope {
@@ -410,18 +478,18 @@ int block_backward_tail(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, con
   RC(linear_wgrad(p, dbig, ws + ba.x2, Mc, m, d, bp.fc1_w, -1, s));
   RC(linear_dgrad(p, dbig, Mc, m, bp.fc1_w, d, dx, HCT_ACT_NONE, nullptr, s));
   RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + ba.h_mid), (const float*)(ws + ba.mean2), (const float*)(ws + ba.rstd2),
-                       p->pf(bp.ln2_w), dhc, Mc, d, dhc, dhs, p->dt, p->gf(bp.ln2_w), p->gf(bp.ln2_b), p->gf(bp.proj_b), ws + p->s_fold_a,
+                       p->pf(bp.ln2_w), dhc, Mc, d, dhc, dhs_mid, p->dt, p->gf(bp.ln2_w), p->gf(bp.ln2_b), p->gf(bp.proj_b), ws + p->s_fold_a,
                        p->s_fold_bytes, s));
   // attention branch: proj on the compact rows, its input gradient scattered back (zeros on the rows the loss never sees)
-  RC(linear_wgrad(p, dhs, ws + p->a_oc, Mc, d, d, bp.proj_w, -1, s));
-  RC(linear_dgrad(p, dhs, Mc, d, bp.proj_w, d, dx, HCT_ACT_NONE, nullptr, s));
+  RC(linear_wgrad(p, dhs_mid, ws + p->a_oc, Mc, d, d, bp.proj_w, -1, s));
+  RC(linear_dgrad(p, dhs_mid, Mc, d, bp.proj_w, d, dx, HCT_ACT_NONE, nullptr, s));
   RC(hct_gather_rows(dx, inv, M, (int)(d * p->esz()), d_o, s));
   RC(hct_attention_bwd(ws + ba.qkv, ws + ba.o, d_o, (const float*)(ws + ba.lse), B, N, heads, d / heads, p->dt, dqkv, s));
   RC(linear_wgrad(p, dqkv, ws + ba.x1, M, 3 * d, d, bp.qkv_w, bp.qkv_b, s));
   RC(linear_dgrad(p, dqkv, M, 3 * d, bp.qkv_w, d, dx, HCT_ACT_NONE, nullptr, s));
   // residual gradient of row r = the compact gradient's row tail_inv[r], nothing for the class token and the kept patches
   RC(hct_layernorm_bwd_mapped(dx, p->dt, h_in, (const float*)(ws + ba.mean1), (const float*)(ws + ba.rstd1), p->pf(bp.ln1_w), dhc, inv, M, d,
-                              dh, dhs, p->dt, p->gf(bp.ln1_w), p->gf(bp.ln1_b), prev_fc2_b >= 0 ? p->gf(prev_fc2_b) : nullptr, ws + p->s_fold_b,
+                              dh, dhs_in, p->dt, p->gf(bp.ln1_w), p->gf(bp.ln1_b), prev_fc2_b >= 0 ? p->gf(prev_fc2_b) : nullptr, ws + p->s_fold_b,
                               p->s_fold_bytes, s));
   return fold_flush(sink, s);
 }
@@ -531,11 +599,30 @@ hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int comput
   const size_t Mx = Md > Me ? Md : Me, Dx = Dd > D ? Dd : D;
   const size_t mlpx = (size_t)(p->Mlp > p->Mlpd ? p->Mlp : p->Mlpd);
   p->s_dh = w.take(Mx * Dx * 4);
-  p->s_dh_shadow = w.take(Mx * Dx * es);
-  p->s_dbig = w.take(Mx * mlpx * es);
+  p->s_dh_shadow = w.take(Mx * Dx * es);  // (gradient wrt a side's first block input in the compute dtype: written, read by nobody)
+  p->s_dbig = p->s_dqkv = 0;              // (per block now: BlockG)
   p->s_dx = w.take(Mx * Dx * es);
   p->s_do = w.take(Mx * Dx * es);
-  p->s_dqkv = w.take(Mx * 3 * Dx * es);
+  // Gradient operands per block (see BlockG): one set per block while that stays under 32 GB per side, otherwise a ring of as
+  // many sets as fit (at least 2: the grouped launches are then flushed every ring - 1 block stages, end_stage).
+  auto alloc_ring = [&](std::vector<BlockG>& ring, int depth, size_t M, size_t d, size_t m) {
+    const size_t set_bytes = M * (5 * d + m) * es, budget = (size_t)32 << 30;
+    int nsets = depth;
+    if (depth > 0 && set_bytes * (size_t)depth > budget) nsets = std::max(2, (int)(budget / set_bytes));
+    nsets = std::min(nsets, depth);
+    for (int i = 0; i < nsets; ++i) {
+      BlockG g;
+      g.out = w.take(M * d * es);
+      g.big = w.take(M * m * es);
+      g.mid = w.take(M * d * es);
+      g.qkv = w.take(M * 3 * d * es);
+      ring.push_back(g);
+    }
+  };
+  alloc_ring(p->genc, c->encoder_depth, Me, D, (size_t)p->Mlp);
+  alloc_ring(p->gdec, p->cfg.decoder_depth, Md, Dd, (size_t)p->Mlpd);
+  p->a_de = w.take(Me * Dd * es);
+  p->a_dtok = w.take(B * K * D * es);
   size_t small = hct_layernorm_bwd_workspace_bytes((int)Mx, (int)Dx);
   small = std::max(small, hct_assemble_bwd_workspace_bytes((int)Dx));
   small = std::max(small, hct_colsum_workspace_bytes((int)Mx, (int)(3 * Dx)));
@@ -571,6 +658,15 @@ hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int comput
   gw = std::max(gw, wgrad_ws(p->dt, batch * p->K, p->D, p->pd));
   p->s_gemm_bytes = gw;
   p->s_gemm = w.take(gw);
+  {  // grouped weight-gradient launches: one workspace (job table + stream-K slabs) per flush slot
+    const char* ev = getenv("HCT_WGRAD_DEFER");
+    p->wg_defer = p->dt == HCT_BF16 && !(ev && ev[0] == '0');
+    const char* eb = getenv("HCT_WGRAD_GROUP_BLOCKS");
+    p->wg_blocks = eb && *eb ? std::max(0, atoi(eb)) : 0;
+    p->s_wg_bytes = hct_gemm_tn_group_workspace_bytes(4 * (c->encoder_depth + p->cfg.decoder_depth) + 4);
+    for (int i = 0; i < kWgSlots; ++i) p->s_wg[i] = p->wg_defer ? w.take(p->s_wg_bytes) : 0;
+  }
+  p->final_off = p->param_elems;
   p->ws_bytes = w.cur;
 
   // ---- named activations (parity tests) ----
@@ -623,6 +719,8 @@ int hct_mae_plan_bind(hct_mae_plan* p, float* params, float* grads, void* params
   p->gemm_ws_armed = false;
   p->nt_ws_armed = false;
   p->fwd_done = false;
+  for (auto& v : p->wg_prepared) v.clear();  // the job tables held the old buffers' addresses
+  p->wg_pending.clear();
   return 0;
 }
 
@@ -738,23 +836,29 @@ int hct_vit_backward_stage(hct_mae_plan* p, int stage, const void* dlatent, void
   unsigned char* ws = p->ws;
   const int B = p->B, ne = p->cfg.encoder_depth;
   float* dh = (float*)(ws + p->s_dh);
-  void* dhs = ws + p->s_dh_shadow;
   void* small = ws + p->s_small;
+  const int Re = (int)p->genc.size();
+  auto enc_out = [&](int i) { return i >= 0 ? p->genc[i % Re].out : p->s_dh_shadow; };  // gradient wrt block i's output (compute dtype)
   if (stage == 0) {  // final norm
     HCT_REQUIRE(dlatent, "hct_vit_backward_stage: stage 0 needs dlatent");
-    return hct_layernorm_bwd(dlatent, p->dt, (const float*)(ws + p->h_enc[ne]), (const float*)(ws + p->a_lat_mean), (const float*)(ws + p->a_lat_rstd),
-                             p->pf(p->p_norm_w), nullptr, p->Me, p->D, dh, dhs, p->dt, p->gf(p->p_norm_w), p->gf(p->p_norm_b),
-                             ne > 0 ? p->gf(p->enc[ne - 1].fc2_b) : nullptr, small, p->s_small_bytes, s);
+    p->wg_pending.clear(); p->wg_slot = 0; p->wg_blocks_pending = 0; p->final_off = p->param_elems;
+    RC(hct_layernorm_bwd(dlatent, p->dt, (const float*)(ws + p->h_enc[ne]), (const float*)(ws + p->a_lat_mean), (const float*)(ws + p->a_lat_rstd),
+                         p->pf(p->p_norm_w), nullptr, p->Me, p->D, dh, ws + enc_out(ne - 1), p->dt, p->gf(p->p_norm_w), p->gf(p->p_norm_b),
+                         ne > 0 ? p->gf(p->enc[ne - 1].fc2_b) : nullptr, small, p->s_small_bytes, s));
+    return end_stage(p, stage, false, false, Re, s);
   }
   if (stage <= ne) {
     const int i = ne - stage;
-    return block_backward(p, p->enc[i], p->aenc[i], (const float*)(ws + p->h_enc[i]), B, p->Ne, p->D, p->Mlp, p->H, i > 0 ? p->enc[i - 1].fc2_b : -1, s);
+    RC(block_backward(p, p->enc[i], p->aenc[i], p->genc[i % Re], enc_out(i - 1), (const float*)(ws + p->h_enc[i]), B, p->Ne, p->D, p->Mlp, p->H,
+                      i > 0 ? p->enc[i - 1].fc2_b : -1, s));
+    return end_stage(p, stage, true, false, Re, s);
   }
   if (stage == ne + 1) {  // input assembly -> patch embedding
-    void* dtok = ws + p->s_do;
+    void* dtok = ws + p->a_dtok;
     RC(hct_vit_assemble_bwd(dh, B, p->L, p->R, p->D, dtok, p->dt, p->gf(p->p_cls), p->p_reg >= 0 ? p->gf(p->p_reg) : nullptr,
                             p->p_pos >= 0 ? p->gf(p->p_pos) : nullptr, s));
-    return linear_wgrad(p, dtok, ws + p->a_patches, B * p->L, p->D, p->pd, p->p_pe_w, p->p_pe_b, s);
+    RC(linear_wgrad(p, dtok, ws + p->a_patches, B * p->L, p->D, p->pd, p->p_pe_w, p->p_pe_b, s));
+    return end_stage(p, stage, false, false, Re, s);
   }
   set_error("hct_vit_backward_stage: stage %d out of range", stage);
   return HCT_E_BADARG;
@@ -767,6 +871,13 @@ int hct_mae_set_loss_grad(hct_mae_plan* p, const float* dloss) {
 }
 
 int hct_mae_num_backward_stages(const hct_mae_plan* p) { return (int)p->stage_range.size(); }
+int64_t hct_mae_backward_final_offset(const hct_mae_plan* p) { return p ? p->final_off : -1; }
+int hct_mae_plan_set_wgrad_defer(hct_mae_plan* p, int defer, int group_blocks) {
+  if (!p) return -1;
+  p->wg_defer = defer != 0 && p->dt == HCT_BF16 && p->s_wg_bytes > 0 && p->s_wg[kWgSlots - 1] != 0;
+  p->wg_blocks = group_blocks > 0 ? group_blocks : 0;
+  return p->wg_defer ? 1 : 0;
+}
 int hct_mae_backward_stage_range(const hct_mae_plan* p, int stage, int64_t* begin, int64_t* end) {
   HCT_REQUIRE(p && stage >= 0 && stage < (int)p->stage_range.size(), "hct_mae_backward_stage_range: bad stage");
   *begin = p->stage_range[stage].first;
@@ -783,11 +894,15 @@ int hct_mae_backward_stage(hct_mae_plan* p, int stage, void* stream) {
   const int B = p->B;
   const int nd = c.decoder_depth, ne = c.encoder_depth;
   float* dh = (float*)(ws + p->s_dh);
-  void* dhs = ws + p->s_dh_shadow;
   void* dx = ws + p->s_dx;
   void* small = ws + p->s_small;
+  const int Re = (int)p->genc.size(), Rd = (int)p->gdec.size();
+  auto enc_out = [&](int i) { return i >= 0 ? p->genc[i % Re].out : p->s_dh_shadow; };  // gradient wrt encoder block i's output (compute dtype)
+  auto dec_out = [&](int i) { return i >= 0 ? p->gdec[i % Rd].out : p->s_dh_shadow; };
   if (stage == 0) {  // loss seed -> decoder_pred -> decoder_norm
     if (!p->dpred_done) { set_error("hct_mae_backward_stage: the last forward ran without grad_scale (inference forward)"); return HCT_E_STATE; }
+    p->wg_pending.clear(); p->wg_slot = 0; p->wg_blocks_pending = 0; p->final_off = p->param_elems;
+    void* dhs = ws + dec_out(nd - 1);
     const int Mt = p->tail_fwd ? p->Mc : p->Md;                       // compact tail: the masked patches' rows only
     float* dht = p->tail_fwd ? (float*)(ws + p->s_dhc) : dh;          // ... whose fp32 gradient has a buffer of its own
     if (p->dloss) RC(scale_unless_one(ws + p->a_dpred, p->dt, (int64_t)Mt * p->pd, p->dloss, s));
@@ -796,17 +911,20 @@ int hct_mae_backward_stage(hct_mae_plan* p, int stage, void* stream) {
     RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + p->h_dec[nd]), (const float*)(ws + p->a_yn_mean), (const float*)(ws + p->a_yn_rstd),
                          p->pf(p->p_dnorm_w), nullptr, Mt, p->Dd, dht, dhs, p->dt, p->gf(p->p_dnorm_w), p->gf(p->p_dnorm_b),
                          nd > 0 ? p->gf(p->dec[nd - 1].fc2_b) : nullptr, small, p->s_small_bytes, s));
-    return 0;
+    return end_stage(p, stage, false, nd == 0, Rd, s);
   }
   if (stage <= nd) {
     const int i = nd - stage;
     if (p->tail_fwd && i == nd - 1)
-      return block_backward_tail(p, p->dec[i], p->adec[i], (const float*)(ws + p->h_dec[i]), i > 0 ? p->dec[i - 1].fc2_b : -1, s);
-    return block_backward(p, p->dec[i], p->adec[i], (const float*)(ws + p->h_dec[i]), B, p->Nd, p->Dd, p->Mlpd, p->Hd,
-                          i > 0 ? p->dec[i - 1].fc2_b : -1, s);
+      RC(block_backward_tail(p, p->dec[i], p->adec[i], p->gdec[i % Rd], dec_out(i - 1), (const float*)(ws + p->h_dec[i]), i > 0 ? p->dec[i - 1].fc2_b : -1, s));
+    else
+      RC(block_backward(p, p->dec[i], p->adec[i], p->gdec[i % Rd], dec_out(i - 1), (const float*)(ws + p->h_dec[i]), B, p->Nd, p->Dd, p->Mlpd, p->Hd,
+                        i > 0 ? p->dec[i - 1].fc2_b : -1, s));
+    return end_stage(p, stage, true, stage == nd, Rd, s);  // (the decoder's products run together once its backward is through)
   }
   if (stage == nd + 1) {  // decoder input assembly -> decoder_embed -> encoder norm
-    void* de = ws + p->s_do;
+    void* de = ws + p->a_de;
+    void* dhs = ws + enc_out(ne - 1);
     RC(hct_decoder_assemble_bwd(dh, (const int32_t*)(ws + p->a_ids_restore), (const int32_t*)(ws + p->a_ids_shuffle), B, p->L, p->K, p->Dd, de,
                                 p->dt, p->gf(p->p_mask), p->gf(p->p_dcls), small, p->s_small_bytes, s));
     RC(linear_wgrad(p, de, ws + p->a_latent, p->Me, p->Dd, p->D, p->p_de_w, p->p_de_b, s));
@@ -814,19 +932,20 @@ int hct_mae_backward_stage(hct_mae_plan* p, int stage, void* stream) {
     RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + p->h_enc[ne]), (const float*)(ws + p->a_lat_mean), (const float*)(ws + p->a_lat_rstd),
                          p->pf(p->p_norm_w), nullptr, p->Me, p->D, dh, dhs, p->dt, p->gf(p->p_norm_w), p->gf(p->p_norm_b),
                          ne > 0 ? p->gf(p->enc[ne - 1].fc2_b) : nullptr, small, p->s_small_bytes, s));
-    return 0;
+    return end_stage(p, stage, false, false, Re, s);
   }
   if (stage <= nd + 1 + ne) {
     const int i = ne - (stage - nd - 1);
-    return block_backward(p, p->enc[i], p->aenc[i], (const float*)(ws + p->h_enc[i]), B, p->Ne, p->D, p->Mlp, p->H,
-                          i > 0 ? p->enc[i - 1].fc2_b : -1, s);
+    RC(block_backward(p, p->enc[i], p->aenc[i], p->genc[i % Re], enc_out(i - 1), (const float*)(ws + p->h_enc[i]), B, p->Ne, p->D, p->Mlp, p->H,
+                      i > 0 ? p->enc[i - 1].fc2_b : -1, s));
+    return end_stage(p, stage, true, false, Re, s);
   }
   if (stage == nd + ne + 2) {  // encoder input assembly -> patch embedding
-    void* dtok = ws + p->s_do;
+    void* dtok = ws + p->a_dtok;
     RC(hct_encoder_assemble_bwd(dh, (const int32_t*)(ws + p->a_ids_restore), B, p->L, p->K, p->D, dtok, p->dt, p->gf(p->p_cls),
                                 p->p_pos >= 0 ? p->gf(p->p_pos) : nullptr, small, p->s_small_bytes, s));
     RC(linear_wgrad(p, dtok, ws + p->a_patches, B * p->K, p->D, p->pd, p->p_pe_w, p->p_pe_b, s));
-    return 0;
+    return end_stage(p, stage, false, false, Re, s);
   }
   set_error("hct_mae_backward_stage: stage %d out of range", stage);
   return HCT_E_BADARG;

@@ -3,9 +3,11 @@
 Replaces `torch.nn.parallel.DistributedDataParallel(model, device_ids=[device], broadcast_buffers=False,
 find_unused_parameters=True)` at main_pretrain_mae.py:139 for the HIP model:
   * construction broadcasts the flat fp32 parameter buffer from rank 0 (DDP ctor semantics);
-  * the native backward runs in stages that each complete one contiguous range of the flat gradient buffer,
-    from its end towards its start (csrc/mae_plan.hip).  After each stage the finished range is appended to
-    the open bucket; once a bucket holds >= bucket_cap_mb it is all-reduced asynchronously
+  * the native backward runs in stages that each compute one contiguous range of the flat gradient buffer,
+    from its end towards its start (csrc/mae_plan.hip); the weight gradients of a few stages run together in one
+    grouped launch, after which the ranges of those stages are final (`wgrad_group_blocks`, default 4 block
+    stages per launch here, against once per decoder / encoder without data parallelism).  Every range that
+    became final is appended to the open bucket; once a bucket holds >= bucket_cap_mb it is all-reduced asynchronously
     (`torch.distributed` backend "nccl" == RCCL; the collective is ordered after the producing kernels on the
     compute stream and runs on the process group's own stream, so it overlaps the remaining backward);
   * the mean over ranks costs nothing: the backward is seeded with dLoss/world_size, so the SUM all-reduce
@@ -53,14 +55,17 @@ class DistributedDataParallel(nn.Module):
             self._reserve = int(os.environ.get("HCT_CU_RESERVE", "16"))
             self._set_reserve = _lib.load().hct_set_cu_reserve
         module._grad_prescale = 1.0 / self.world_size
+        if self.world_size > 1 and getattr(module, "wgrad_group_blocks", 0) is None:
+            import os
+            module.wgrad_group_blocks = int(os.environ.get("HCT_WGRAD_GROUP_BLOCKS", "4"))
         module._bucket_hook = self._on_stage
         module._post_backward_hook = self._finish
 
-    # called by the model after backward stage `stage` has been enqueued; [begin, end) is now final
+    # called by the model after backward stage `stage` has been enqueued when a gradient range became final: [begin, end)
     def _on_stage(self, stage: int, begin: int, end: int) -> None:
         if self.world_size == 1:
             return
-        if stage == 0:
+        if end == self.module._flat_grad.numel():  # first range of a backward
             self.launched = []
         if self._open is None:
             self._open = (begin, end)

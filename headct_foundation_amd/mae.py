@@ -176,7 +176,8 @@ class FlatPlanModule(nn.Module):
         self._plans: Dict[int, _Plan] = {}
         self._weights_version = 0      # bumped whenever fp32 master weights may have changed
         self._shadow_version = -1      # version the bf16 working copies correspond to
-        self._bucket_hook: Optional[Callable[[int, int, int], None]] = None  # (stage, begin, end) after each stage
+        self._bucket_hook: Optional[Callable[[int, int, int], None]] = None  # (stage, begin, end): gradient range that became final
+        self.wgrad_group_blocks: Optional[int] = None  # data parallelism: flush the queued weight gradients every n block stages
         self._post_backward_hook: Optional[Callable[[], None]] = None
         self._grad_overwrite = True    # next backward overwrites the flat gradient (set by zero_grad paths)
         self._grad_prescale = 1.0
@@ -323,11 +324,19 @@ class FlatPlanModule(nn.Module):
         if not self._grad_overwrite and any(p.grad is not None for p in self.parameters()):
             self._attach_grads()  # a foreign / preset .grad tensor is folded into the flat buffer first
             parked = self._flat_grad.clone()
+        # weight gradients are queued across stages and run in grouped launches (csrc/mae_plan.hip: flush_wgrads), so a stage's
+        # range is final only when the plan's watermark has passed it: the bucket hook gets [watermark, previous watermark)
+        if self._bucket_hook is not None and getattr(self, "wgrad_group_blocks", None) is not None and getattr(plan, "_wg_blocks", None) != self.wgrad_group_blocks:
+            lib.hct_mae_plan_set_wgrad_defer(plan.handle, 1, int(self.wgrad_group_blocks))
+            plan._wg_blocks = self.wgrad_group_blocks
+        final = self._flat_grad.numel()
         for s in range(plan.nstages):
             _lib.check(stage_call(s), f"{what}({s})")
             if self._bucket_hook is not None:
-                b, e = plan.stage_ranges[s]
-                self._bucket_hook(s, b, e)
+                now = int(lib.hct_mae_backward_final_offset(plan.handle))
+                if now < final:
+                    self._bucket_hook(s, now, final)
+                    final = now
         if self._post_backward_hook is not None:
             self._post_backward_hook()  # data parallel: the compute stream now waits for the collectives
         if parked is not None:

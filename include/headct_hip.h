@@ -390,11 +390,20 @@ int hct_mae_forward(hct_mae_plan*, const void* x, int x_dtype, const float* nois
 /* device pointer to the scalar dLoss that multiplies the backward's seed (NULL = 1.0; a value of 1.0 costs nothing). */
 int hct_mae_set_loss_grad(hct_mae_plan*, const float* dloss);
 /* backward in stages so the host can launch the per-bucket gradient all-reduce between them:
- * stage 0 .. hct_mae_num_backward_stages()-1, in order; each stage finishes the gradients of the
- * parameter range reported by hct_mae_backward_stage_range (element offsets into the flat buffer). */
+ * stage 0 .. hct_mae_num_backward_stages()-1, in order; stage s computes the gradients of the parameter range reported by
+ * hct_mae_backward_stage_range (element offsets into the flat buffer; the ranges tile the buffer from its end to its start).
+ * In bf16 plans the WEIGHT gradients (dW = dY^T . X, which feed nothing in the backward) of several stages are queued and run
+ * together in one grouped launch (hct_gemm_tn_group_*): a range is therefore FINAL only once
+ * hct_mae_backward_final_offset() -- every element at or behind it is final -- has moved down to its begin; after the last
+ * stage it is 0.  hct_mae_plan_set_wgrad_defer(plan, defer, group_blocks): defer = 0 runs every weight gradient inside its stage
+ * (split-K launches, ranges final stage by stage); group_blocks > 0 flushes the queue at least every that many block stages
+ * (default 0: once after the decoder's and once after the encoder's backward); returns the mode in effect.  Environment at plan
+ * creation: HCT_WGRAD_DEFER=0, HCT_WGRAD_GROUP_BLOCKS=n. */
 int hct_mae_num_backward_stages(const hct_mae_plan*);
 int hct_mae_backward_stage_range(const hct_mae_plan*, int stage, int64_t* begin, int64_t* end);
 int hct_mae_backward_stage(hct_mae_plan*, int stage, void* stream);
+int64_t hct_mae_backward_final_offset(const hct_mae_plan*);
+int hct_mae_plan_set_wgrad_defer(hct_mae_plan*, int defer, int group_blocks);
 /* Plain ViT backbone (plans created with encoder_only = 1).  forward: x [B,C,S,S,S] -> "latent" [B*(1+R+L), D] in the compute
  * dtype = norm(blocks(...)) of every token (hct_mae_plan_activation(plan, "latent")); row b*(1+R+L) is volume b's class token.
  * backward: stages 0 .. hct_mae_num_backward_stages()-1 like the MAE plan (final norm, blocks in reverse, input assembly + patch

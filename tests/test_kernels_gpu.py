@@ -193,6 +193,79 @@ def test_gemm_tn_bf16_mfma(lib, cuda, R, M, N):
     assert torch.equal(out, fused) and torch.equal(fused, fused2)
 
 
+def _tn_group(lib, ops, reps=1):
+    """ops: list of (A [R,M] bf16, B [R,N] bf16, alpha).  Returns the fp32 products of the grouped launch (last repetition)."""
+    n = len(ops)
+    jobs = (GemmArgs * n)()
+    outs = []
+    for i, (A, B, alpha) in enumerate(ops):
+        R, M = A.shape
+        N = B.shape[1]
+        Cm = torch.full((M, N), float("nan"), device=A.device)
+        outs.append(Cm)
+        a = jobs[i]
+        a.M, a.N, a.K = M, N, R
+        a.A, a.a_dtype, a.lda, a.transA = A.data_ptr(), HCT_BF16, A.stride(0), 1
+        a.B, a.b_dtype, a.ldb, a.transB = B.data_ptr(), HCT_BF16, B.stride(0), 0
+        a.C, a.c_dtype, a.ldc = Cm.data_ptr(), HCT_F32, N
+        a.alpha = alpha
+    nbytes = lib.hct_gemm_tn_group_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=ops[0][0].device)
+    _lib.check(lib.hct_gemm_tn_group_prepare(C.cast(jobs, C.c_void_p), n, ws.data_ptr(), nbytes, _st()), "tn_group_prepare")
+    for _ in range(reps):
+        _lib.check(lib.hct_gemm_tn_group_run(C.cast(jobs, C.c_void_p), n, ws.data_ptr(), nbytes, _st()), "tn_group_run")
+    torch.cuda.synchronize()
+    flags = ws[lib.hct_gemm_tn_group_workspace_bytes(n) - (256 * 262144 + 4096):][:4096].view(torch.int32)
+    assert int(flags[512]) == 0, "a stream-K partial of the grouped wgrad never arrived"
+    return outs
+
+
+@pytest.mark.parametrize("case", ["stream_k_only", "rounds_plus_remainder", "mixed_small", "one_tile", "reserve16"])
+def test_gemm_tn_group(lib, cuda, case):
+    """Grouped weight gradients (one persistent launch, whole 256x256 tiles over the full reduction + a stream-K remainder round):
+    every product against a float reference (bf16 products are exact in fp32: 2e-5), repeat launches bit-identical, and the same
+    bits on a 240-workgroup grid split differently (reserve16: different partial sums, so 1e-5 rather than bit equality)."""
+    shapes = {
+        # (R, M, N) per job: 108 tiles on 256 CUs -> no whole round, every tile shared by 2-3 workgroups
+        "stream_k_only": [(2000, 768, 3072), (2000, 3072, 768), (2016, 768, 768), (2000, 2304, 768)],
+        # 8 x 72 = 576 tiles -> two whole rounds + 64 remainder tiles; two reduction lengths
+        "rounds_plus_remainder": [(300, 1536, 3072)] * 5 + [(1000, 3072, 1536)] * 3,
+        "mixed_small": [(130, 48, 64), (33, 16, 16), (4000, 272, 528), (257, 768, 16)],
+        "one_tile": [(5000, 256, 256)],
+        "reserve16": [(2000, 768, 3072), (2000, 3072, 768), (2016, 768, 768), (2000, 2304, 768)],
+    }[case]
+    ops = []
+    for i, (R, M, N) in enumerate(shapes):
+        ops.append((_rand((R, M), cuda, torch.bfloat16, 100 + i), _rand((R, N), cuda, torch.bfloat16, 200 + i, 0.1), 1.0 if i % 2 == 0 else 0.5))
+    if case == "reserve16":
+        lib.hct_set_cu_reserve(16)
+    try:
+        got = _tn_group(lib, ops)
+        again = _tn_group(lib, ops, reps=3)
+    finally:
+        lib.hct_set_cu_reserve(0)
+    for (A, B, alpha), g, g2 in zip(ops, got, again):
+        want = alpha * (A.float().t() @ B.float())
+        assert torch.isfinite(g).all()
+        assert rel_err(g, want) < 2e-5, (case, tuple(A.shape), tuple(B.shape))
+        assert torch.equal(g, g2), "grouped wgrad is not bit-reproducible"
+
+
+def test_gemm_tn_group_rejects_other_products(lib, cuda):
+    A, B = _rand((64, 32), cuda, torch.bfloat16, 1), _rand((64, 48), cuda, torch.bfloat16, 2)
+    jobs = (GemmArgs * 1)()
+    a = jobs[0]
+    a.M, a.N, a.K = 32, 48, 64
+    a.A, a.a_dtype, a.lda, a.transA = A.data_ptr(), HCT_BF16, 32, 0  # not transposed: not a wgrad
+    a.B, a.b_dtype, a.ldb, a.transB = B.data_ptr(), HCT_BF16, 48, 0
+    Cm = torch.empty(32, 48, device=cuda)
+    a.C, a.c_dtype, a.ldc, a.alpha = Cm.data_ptr(), HCT_F32, 48, 1.0
+    n = lib.hct_gemm_tn_group_workspace_bytes(1)
+    ws = torch.empty(n, dtype=torch.uint8, device=cuda)
+    assert lib.hct_gemm_tn_group_prepare(C.cast(jobs, C.c_void_p), 1, ws.data_ptr(), n, _st()) != 0
+    assert lib.hct_gemm_tn_group_prepare(C.cast(jobs, C.c_void_p), 1, ws.data_ptr(), 16, _st()) != 0  # workspace too small
+
+
 def test_gemm_generic_fp32_all_layouts(lib, cuda):
     M, N, K = 77, 53, 45
     A, B = _rand((M, K), cuda, torch.float32, 7), _rand((K, N), cuda, torch.float32, 8)
