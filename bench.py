@@ -130,14 +130,23 @@ def run_dino(args, world, rank, device):
             dist.barrier()
         torch.cuda.synchronize()
 
+    from headct_foundation_amd import _lib
+    lib = _lib.load()
     for i in range(args.warmup):
         step(i)
     fence()
+    prof = not args.no_prof
+    if prof:
+        lib.hct_prof_reset()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
+        if prof:  # the dominant kernel's launches (the same NT GEMM instances as the MAE step) bracketed on every 4th timed step
+            lib.hct_prof_enable((0x1F if args.prof_all else 0x1) if (i - args.warmup) % 4 == 0 else 0)
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
+    if prof:
+        lib.hct_prof_enable(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -145,6 +154,7 @@ def run_dino(args, world, rank, device):
     lv = losses.cpu()
     if not torch.isfinite(lv).all():
         raise SystemExit(f"non-finite loss during the benchmark: {lv.tolist()}")
+    roof, extra = roofline_from_events(lib, args.steps, elapsed, "dino") if prof else (None, {})
     if rank == 0:
         fl = dino_train_flops_per_volume(DINO)
         vols = B * G * args.steps
@@ -156,24 +166,59 @@ def run_dino(args, world, rank, device):
             "config": {"workload": "BASELINE config #5: DINO, ViT-B/12^3 (517 tokens, 4 register tokens), head 768-2048-2048-256-65536, full iteration",
                        "per_gpu_batch": B, "global_batch": B * G, "crops_per_volume": V, "parallelism": f"dp{G}",
                        "algorithmic_GFLOP_per_volume": round(fl / 1e9, 1)},
-            "step_mfma_frac": round(vols / elapsed * fl / G / 1e12 / PEAK_BF16_TFLOPS, 4), "roofline": None,
+            "step_mfma_frac": round(vols / elapsed * fl / G / 1e12 / PEAK_BF16_TFLOPS, 4), "roofline": roof, "other_kernels": extra or None,
             "loss_first": round(float(lv[0]), 5), "loss_last": round(float(lv[-1]), 5)}), flush=True)
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (separate passes cannot run
-    inside the timed region); None if no summary is present."""
+def pmc_traffic(config: str = "vitb"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary OF THIS CONFIGURATION (separate passes
+    cannot run inside the timed region); None if there is none.  Files: profiles/r<NN>[_tag]_pmc_nt256[_<config>].json -- no
+    config suffix = vitb (config #2); the highest round wins, then the untagged file of that round."""
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_nt256.json")))
-    if not cands:
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_nt256*.json")):
+        m = re.match(r"r(\d+)(?:_([a-z0-9]+))?_pmc_nt256(?:_([a-z]+))?\.json$", os.path.basename(f))
+        if not m or (m.group(3) or "vitb") != config:
+            continue
+        key = (int(m.group(1)), m.group(2) is None, m.group(2) or "")
+        if best is None or key > best[0]:
+            best = (key, f)
+    if best is None:
         return None
     try:
-        with open(cands[-1]) as f:
+        with open(best[1]) as f:
             d = json.load(f)
-        return {"hbm_bytes_per_launch": round(d["hbm_bytes_per_launch"]), "source": os.path.relpath(cands[-1], ROOT),
+        return {"hbm_bytes_per_launch": round(d["hbm_bytes_per_launch"]), "source": os.path.relpath(best[1], ROOT),
                 "note": "2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), gfx950 FETCH_SIZE correction applied"}
     except Exception:
         return None
+
+
+def roofline_from_events(lib, steps: int, elapsed: float, config: str):
+    """`roofline` object of the JSON line from the HIP events the library recorded around the NT GEMM launches of the sampled steps
+    (every 4th timed step), plus the other kernel classes if they were timed."""
+    sampled = (steps + 3) // 4
+    ms, n, w, nt_bytes = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+    from headct_foundation_amd import _lib
+    _lib.check(lib.hct_prof_read(0, C.byref(ms), C.byref(n), C.byref(w)), "hct_prof_read")
+    _lib.check(lib.hct_prof_read_bytes(0, C.byref(nt_bytes)), "hct_prof_read_bytes")
+    roof, extra = None, {}
+    traf = pmc_traffic(config)
+    if n.value and ms.value > 0:
+        ach = w.value / (ms.value * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_nt256_kernel<*> (all epilogue modes)", "achieved": round(ach, 2),
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": (traf or {}).get("hbm_bytes_per_launch"), "traffic_detail": traf,
+                "algorithmic_TFLOP_per_launch": round(w.value / n.value / 1e12, 4),
+                "algorithmic_bytes_per_launch": round(nt_bytes.value / n.value),
+                "launches_per_step": n.value // max(1, sampled), "sampled_steps": sampled, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+                "time_share_of_step": round(ms.value * 1e-3 * steps / sampled / elapsed, 4)}
+    for kid, name in ((1, "gemm_bf16_tn (grouped weight gradients)"), (3, "attention_fwd"), (4, "attention_bwd"), (2, "gemm_generic")):
+        _lib.check(lib.hct_prof_read(kid, C.byref(ms), C.byref(n), C.byref(w)), "hct_prof_read")
+        if n.value and ms.value > 0:
+            extra[name] = {"TFLOP/s": round(w.value / (ms.value * 1e-3) / 1e12, 2), "time_share_of_step": round(ms.value * 1e-3 * steps / sampled / elapsed, 4)}
+    lib.hct_prof_reset()
+    return roof, extra
 
 
 def _host_threads() -> int:
@@ -315,26 +360,7 @@ def main():
     if not torch.isfinite(lv).all():
         raise SystemExit(f"non-finite loss during the benchmark: {lv.tolist()}")
 
-    roof = None
-    traf = pmc_traffic()
-    if prof:
-        ms, n, w, nt_bytes = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
-        _lib.check(lib.hct_prof_read(0, C.byref(ms), C.byref(n), C.byref(w)), "hct_prof_read")
-        _lib.check(lib.hct_prof_read_bytes(0, C.byref(nt_bytes)), "hct_prof_read_bytes")
-        if n.value and ms.value > 0:
-            ach = w.value / (ms.value * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_bf16_nt256_kernel<*> (all epilogue modes)", "achieved": round(ach, 2),
-                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": (traf or {}).get("hbm_bytes_per_launch"), "traffic_detail": traf,
-                    "algorithmic_TFLOP_per_launch": round(w.value / n.value / 1e12, 4),
-                    "algorithmic_bytes_per_launch": round(nt_bytes.value / n.value),
-                    "launches_per_step": n.value // max(1, (args.steps + 3) // 4), "sampled_steps": (args.steps + 3) // 4, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
-                    "time_share_of_step": round(ms.value * 1e-3 * args.steps / ((args.steps + 3) // 4) / elapsed, 4)}
-        extra = {}
-        for kid, name in ((1, "gemm_bf16_tn_kernel"), (3, "attention_fwd"), (4, "attention_bwd"), (2, "gemm_generic")):
-            _lib.check(lib.hct_prof_read(kid, C.byref(ms), C.byref(n), C.byref(w)), "hct_prof_read")
-            if n.value and ms.value > 0:
-                extra[name] = {"TFLOP/s": round(w.value / (ms.value * 1e-3) / 1e12, 2), "time_share_of_step": round(ms.value * 1e-3 * args.steps / ((args.steps + 3) // 4) / elapsed, 4)}
-        lib.hct_prof_reset()
+    roof, extra = roofline_from_events(lib, args.steps, elapsed, args.config) if prof else (None, {})
     if rank == 0:
         vols = B * G * args.steps
         flops_vol = algorithmic_train_flops_per_volume(arch)

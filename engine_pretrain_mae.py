@@ -10,11 +10,17 @@ reference keep working.  What differs underneath:
     autocast region and therefore nothing to scale: `use_amp` is accepted and ignored, a GradScaler passed in is still
     honoured step by step (scale / unscale_ / step / update) so foreign callers see the behaviour they asked for;
   * gradient clipping and AdamW are single fused launches without host round trips (headct_foundation_amd/optim.py);
-  * the loss is fetched once per iteration because the reference logs every iteration.
+  * the reference synchronises the device and reads the loss back in every iteration (engine_pretrain_mae.py:73-74) because it
+    logs every iteration.  Here the log line of iteration i is written while iteration i + 1 is already queued: the loss goes to
+    a pinned host buffer by an asynchronous copy and is read one iteration later (`_LossTap`), so the device never idles
+    waiting for the host between steps; same lines, same order, same values, the finite-loss check one iteration late.
+    HCT_SYNC_LOSS=1 restores the reference's per-iteration synchronisation.
 """
 import math
+import os
 import sys
 import time
+from collections import deque
 from typing import Any, Dict, Iterable, Optional
 
 import torch
@@ -39,6 +45,36 @@ def _drain() -> None:
         torch.cuda.synchronize()
 
 
+class _LossTap:
+    """Loss values without a per-iteration device synchronisation: `push` queues a device -> pinned-host copy of the (rank-mean)
+    loss behind the step that produced it, `pop` hands back the entries whose copy has completed, waiting for the oldest only
+    when more than `depth` iterations are in flight (or at the end of the epoch)."""
+
+    def __init__(self, depth: int = 1):
+        self.depth, self.q = depth, deque()
+
+    def push(self, loss: torch.Tensor, meta) -> None:
+        v = all_reduce_mean(loss)
+        v = v if isinstance(v, torch.Tensor) else torch.as_tensor(float(v))
+        if v.is_cuda:
+            host = torch.empty((), dtype=torch.float32, pin_memory=True)
+            host.copy_(v.detach().float().reshape(()), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = v.detach().float().reshape(()).clone(), None
+        self.q.append((host, ev, meta))
+
+    def pop(self, flush: bool = False):
+        out = []
+        while self.q and (flush or len(self.q) > self.depth or self.q[0][1] is None or self.q[0][1].query()):
+            host, ev, meta = self.q.popleft()
+            if ev is not None:
+                ev.synchronize()
+            out.append((float(host), meta))
+        return out
+
+
 def _finish_epoch(meters: MetricLogger, logger) -> Dict[str, float]:
     meters.synchronize_between_processes()
     logger.info(f"Averaged stats: {meters}")
@@ -52,6 +88,19 @@ def train_one_epoch(config: Any, model: torch.nn.Module, loader: Iterable, optim
     meters = MetricLogger(delimiter="  ", logger=logger)
     clip = config.TRAIN.GRAD_CLIP
     n_iter = len(loader)
+    sync_every_step = os.environ.get("HCT_SYNC_LOSS") == "1"
+    tap = _LossTap(depth=0 if sync_every_step else 1)
+
+    def report(flush: bool) -> None:
+        for value, (it_, lr_) in tap.pop(flush):
+            if not math.isfinite(value):
+                logger.info(f"Loss is {value}, stopping training")
+                sys.exit(1)
+            meters.update(loss=value, lr=lr_)
+            logger.info(f"Epoch {epoch+1}/{max_epoch} [{it_}/{n_iter}]  Loss: {value:.4f}")
+            if wandb_run is not None and get_rank() == 0:
+                wandb_run.log({'Training Loss': value, 'Training lr': lr_})
+
     for it, batch in enumerate(loader, start=1):
         optimizer.zero_grad()
         loss = _loss_of(config, model, batch, device)
@@ -68,16 +117,12 @@ def train_one_epoch(config: Any, model: torch.nn.Module, loader: Iterable, optim
             scaler.step(optimizer)
             scaler.update()
         scheduler.step()
-        _drain()
-        value = _as_float(loss)
-        if not math.isfinite(value):
-            logger.info(f"Loss is {value}, stopping training")
-            sys.exit(1)
-        lr = optimizer.param_groups[0]["lr"]
-        meters.update(loss=value, lr=lr)
-        logger.info(f"Epoch {epoch+1}/{max_epoch} [{it}/{n_iter}]  Loss: {value:.4f}")
-        if wandb_run is not None and get_rank() == 0:
-            wandb_run.log({'Training Loss': value, 'Training lr': lr})
+        if sync_every_step:
+            _drain()
+        # (the rate logged beside it is read after scheduler.step(), as the reference does)
+        tap.push(loss, (it, optimizer.param_groups[0]["lr"]))
+        report(flush=sync_every_step)
+    report(flush=True)
     return _finish_epoch(meters, logger)
 
 

@@ -126,6 +126,7 @@ _PROTOS = {
                                c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "hct_debug_set_gemm_variant": (None, [c_int]),
     "hct_debug_set_gemm_stagger": (None, [c_int]),
+    "hct_gemm_nt_stream_k_bytes": (c_size_t, []),
     "hct_gemm_tn_group_workspace_bytes": (c_size_t, [c_int]),
     "hct_gemm_tn_group_prepare": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "hct_gemm_tn_group_run": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

@@ -26,6 +26,7 @@ static int g_stagger = -1;  // -1 auto, >= 0 forced (testing)
 static int g_tn_separate_fold = 1;  // 1 = split partials folded by gemm_fold_kernel; 0 = inside the wgrad launch (measured 0.36 ms per step SLOWER:
                                      // DESIGN.md section 5; kept selectable and tested, -6 / -7 of hct_debug_set_gemm_variant)
 static int g_nt_variant = 0;  // 0 auto; 128 / 256 / 4 force one NT kernel (tests cover every instance)
+static int g_sk_drop = 0;     // testing (hct_debug_set_gemm_variant(-8 / -9)): stream-K followers publish a wrong sequence number -> every owner times out
 
 struct Epilogue {
   const float* bias;
@@ -840,6 +841,10 @@ constexpr size_t kSkHeadBytes = 4096, kSkSlabBytes = 262144;
 constexpr size_t kSkBytes = kSkHeadBytes + (size_t)kSkMaxWgs * kSkSlabBytes;
 constexpr int kSkErrWord = 512;
 
+// what a follower publishes: the launch's sequence number -- or, with the debug bit 31 of the kernel argument set
+// (hct_debug_set_gemm_variant(-8): test of the time-out path), a wrong one, so that every owner times out
+__device__ __forceinline__ unsigned sk_pub(unsigned seq_arg) { return ((seq_arg >> 31) ? seq_arg + 1u : seq_arg) & 0x0FFFFFFFu; }
+
 __device__ __forceinline__ uint32_t xcc_id() {  // the XCD (accelerator die) this wave runs on
   uint32_t v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
@@ -1175,7 +1180,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0)  // flag = launch sequence number | the XCD this workgroup really runs on
-        __hip_atomic_store((unsigned*)sk_ws + blockIdx.x, (sk_seq << 4) | xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((unsigned*)sk_ws + blockIdx.x, (sk_pub(sk_seq) << 4) | xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       younger = 0;  // (everything was drained for the flag)
     } else {
       younger = 1;
@@ -1184,6 +1189,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
         // write-through and drained before the flag; the poll is relaxed, ONE agent-scope acquire then drops this CU's stale
         // lines before the plain loads (the protocol of the wgrad's in-launch fold; MI355X_MICROARCH.md, "Valid forms").
         const int c_end = (int)blockIdx.x + 8 * (1 + (int)((item >> 28) & 7));
+        int& s_bad = *reinterpret_cast<int*>(smem + 5 * 32768 - 16);  // (end of the last epilogue patch: free until the epilogue below)
         for (int c2 = blockIdx.x + 8; c2 < c_end; c2 += 8) {  // the next workgroups of this XCD
           if (threadIdx.x == 0) {
             unsigned spins = 0, f;
@@ -1192,7 +1198,13 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
               __builtin_amdgcn_s_sleep(8);
               ++spins;
             }
-            if (spins >= (1u << 20))  // cannot happen with a resident grid: flag it (hct_gemm_nt_flags_offset) instead of hanging the GPU
+            // A partial that never arrives cannot happen while the whole grid is resident (a follower never waits), but a grid that
+            // is NOT resident is possible -- e.g. a communication kernel holding more CUs than hct_set_cu_reserve left free.  The
+            // error word (hct_gemm_nt_flags_offset) is set AND the tile is poisoned with NaN below: the loss of this or the next
+            // step is then not finite, which the engine checks every step (engine_pretrain_mae.py:76-78), instead of training on
+            // silently wrong numbers.
+            s_bad = spins >= (1u << 20);
+            if (spins >= (1u << 20))
               __hip_atomic_store((unsigned*)sk_ws + kSkErrWord, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // Same XCD (the rule, see the item set-up): the slab was written THROUGH this XCD's L2 and is read below by loads that
             // bypass the vector L1 (sc1), so nothing has to be invalidated.  Another XCD: agent-scope acquire first -- it drops the
@@ -1218,6 +1230,14 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
 #pragma unroll
               for (int j = 0; j < 8; ++j) acc[i + u][j] += v[u][j];
           }
+          if (s_bad) {
+            const float nanv = __builtin_nanf("");
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{nanv, nanv, nanv, nanv};
+          }
+          __syncthreads();  // (s_bad is rewritten by the next follower's poll)
         }
       }
       // generic: ring buffers 3 and 4 (8 KiB per wave), refilled only after the next tile's first barrier; specialised: buffer 4
@@ -1667,10 +1687,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if (s_timeout) {  // a split never arrived (cannot happen with a resident grid): flag it instead of hanging the GPU
-      if (threadIdx.x == 0) __hip_atomic_store(counters + 128, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      continue;
-    }
+    const bool fold_bad = s_timeout != 0;  // a split never arrived (cannot happen with a resident grid): flag it, poison this share with NaN
+    if (fold_bad && threadIdx.x == 0) __hip_atomic_store(counters + 128, 0xDEADu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // this workgroup's share of the tile: rows [r0, r1)
     const int r0 = (fsp * 256) / splits, r1 = ((fsp + 1) * 256) / splits;
     const int cols4 = 64;  // 256 columns as float4
@@ -1708,7 +1726,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        if (dst[k]) *reinterpret_cast<f32x4*>(dst[k]) = sum[k] * e.alpha;
+        if (dst[k]) *reinterpret_cast<f32x4*>(dst[k]) = fold_bad ? f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")} : sum[k] * e.alpha;
     }
     // last one out re-arms the tile's counters for the next launch on this workspace
     __syncthreads();
@@ -1975,7 +1993,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob*
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0)
-        __hip_atomic_store((unsigned*)sk_ws + q, (sk_seq << 4) | xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((unsigned*)sk_ws + q, (sk_pub(sk_seq) << 4) | xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (more) {  // the drain above also waited for the next item's first stages; nothing else to restore
       }
     } else {
@@ -2268,7 +2286,9 @@ static bool nt_stream_k(const hct_gemm_args* a, int tiles256, int& sk_tiles, int
   const int gx = G / 8, nxmax = (rem + 7) / 8;
   if (G % 8 || (int64_t)nxmax * P > (int64_t)gx * (P - 1)) return false;
   sk_tiles = rem;
-  sk_wgs = (int)std::min<int64_t>(gx, std::max<int64_t>(1, (int64_t)(rem / 8) * P / 4));  // workgroups per XCD that may take a K range
+  // workgroups per XCD that may take a K range: one per four stage pairs of the XCD's share of the remainder tiles, ceil(rem / 8)
+  // of them (rem / 8 gave ONE workgroup per XCD for rem < 8: a stream-K launch that shared nothing)
+  sk_wgs = (int)std::min<int64_t>(gx, std::max<int64_t>(1, (int64_t)((rem + 7) / 8) * P / 4));
   return true;
 }
 
@@ -2293,6 +2313,7 @@ extern "C" {
 void hct_set_cu_reserve(int n) { g_cu_reserve = n < 0 ? 0 : n; }
 void hct_debug_set_gemm_variant(int v) {
   if (v == -4 || v == -5) { g_w4_auto = v == -4; return; }
+  if (v == -8 || v == -9) { g_sk_drop = v == -8; return; }
   if (v <= -1000) { g_sk_min_k = -v - 1000; return; }       // stream-K of the NT remainder round only for K >= this (huge: off)
   if (v <= -100) { g_sk_gain_pairs = -v - 100; return; }     // ... and only where it saves at least this many stage pairs per CU
   if (v == -6 || v == -7) { g_tn_separate_fold = v == -6; return; }  // -6 / -7: separate fold kernel for the wgrad splits on / off  // -4 / -5: auto-dispatch of the 2-WG/CU variant on / off
@@ -2317,7 +2338,13 @@ static size_t colsum_ws256(const hct_gemm_args* a) { return (colsum_ws(a) + 255)
 size_t hct_gemm_workspace_bytes(const hct_gemm_args* a) {
   // NT: column-sum partials (if asked for) at the head; the stream-K region of the persistent kernel at the tail (optional: a
   // caller that passes less, or no workspace, gets whole tiles only)
-  if (choose_path(a) == PATH_NT) return a->K % 64 == 0 && a->K >= 512 ? colsum_ws256(a) + kSkBytes : colsum_ws(a);
+  // (only where the remainder round of THIS shape would be shared out on the present CU count: a caller that allocates per call
+  //  -- the DINO head's Linears -- then neither reserves 64 MiB nor resets flags for shapes that never split)
+  if (choose_path(a) == PATH_NT) {
+    int sk_tiles = 0, sk_wgs = 0;
+    const bool sk = a->K % 64 == 0 && a->K >= 128 && nt_stream_k(a, ((a->M + 255) / 256) * ((a->N + 255) / 256), sk_tiles, sk_wgs);
+    return sk ? colsum_ws256(a) + kSkBytes : colsum_ws(a);
+  }
   if (choose_path(a) != PATH_TN) return colsum_ws(a);
   int splits, r_chunk;
   if (tn256_ok(a)) {
@@ -2328,6 +2355,7 @@ size_t hct_gemm_workspace_bytes(const hct_gemm_args* a) {
   return splits > 1 ? (size_t)splits * a->M * a->N * sizeof(float) : 0;
 }
 
+size_t hct_gemm_nt_stream_k_bytes(void) { return kSkBytes; }
 size_t hct_gemm_nt_flags_offset(size_t workspace_bytes) {
   return workspace_bytes >= kSkBytes ? ((workspace_bytes - kSkBytes) & ~(size_t)255) : (size_t)-1;
 }
@@ -2426,6 +2454,7 @@ int hct_gemm_tn_group_run(const hct_gemm_args* jobs, int n, void* workspace, siz
   static unsigned seq = 0;
   unsigned sk_seq = (++seq) & 0x0FFFFFFFu;
   if (sk_seq == 0) sk_seq = (++seq) & 0x0FFFFFFFu;
+  if (g_sk_drop) sk_seq |= 0x80000000u;
   hipLaunchKernelGGL(gemm_bf16_tn_group_kernel, dim3(G), dim3(512), 0, s, (const TnJob*)workspace, n, T, F, (int)S_rem, W,
                      (unsigned char*)workspace + tn_group_table_bytes(n), sk_seq);
   HCT_CHECK_LAUNCH("hct_gemm_tn_group_run");
@@ -2506,6 +2535,7 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
         static unsigned seq = 0;
         sk_seq = (++seq) & 0x0FFFFFFFu;  // (28 bits: the flag word also carries the writer's XCD)
         if (sk_seq == 0) sk_seq = (++seq) & 0x0FFFFFFFu;  // zero is what an armed region starts from
+        if (g_sk_drop) sk_seq |= 0x80000000u;
         if (!a->workspace_armed)
           if (int rc = check_hip(hipMemsetAsync(sk_ws, 0, kSkHeadBytes, s), "hct_gemm(nt256): stream-K flag reset")) return rc;
       }

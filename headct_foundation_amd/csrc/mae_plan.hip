@@ -346,13 +346,13 @@ int flush_wgrads(hct_mae_plan* p, hipStream_t s) {
 }
 
 // end of backward stage `stage`: flush where the policy says so, then move the "final" watermark
-int end_stage(hct_mae_plan* p, int stage, bool block_stage, bool boundary, int ring, hipStream_t s) {
+int end_stage(hct_mae_plan* p, int stage, bool block_stage, bool boundary, int ring, int depth, hipStream_t s) {
   if (block_stage) ++p->wg_blocks_pending;
   const bool last = stage + 1 == (int)p->stage_range.size();
-  // a ring of r gradient-operand sets allows at most r - 1 block stages between flushes (the r-th block would overwrite the
-  // output gradient that the oldest queued product still reads)
+  // a ring of r < depth gradient-operand sets allows at most r - 1 block stages between flushes (the r-th block would overwrite
+  // the output gradient that the oldest queued product still reads); with one set per block nothing is ever overwritten
   int limit = p->wg_blocks > 0 ? p->wg_blocks : (1 << 30);
-  if (ring > 0 && ring - 1 < limit) limit = ring - 1;
+  if (ring > 0 && ring < depth && ring - 1 < limit) limit = ring - 1;
   if (last || boundary || p->wg_blocks_pending >= limit) RC(flush_wgrads(p, s));
   if (p->wg_pending.empty()) p->final_off = p->stage_range[stage].first;
   return 0;
@@ -638,11 +638,7 @@ hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int comput
   p->s_small_bytes = small;
   p->s_small = w.take(small);
   if (p->dt == HCT_BF16) {  // stream-K region of the persistent NT GEMM, directly behind s_small (see nt_gemm)
-    hct_gemm_args a = base_args();
-    a.M = 256; a.N = 256; a.K = 512;
-    a.a_dtype = a.b_dtype = a.c_dtype = HCT_BF16; a.lda = a.ldb = 512; a.ldc = 256; a.transA = 0; a.transB = 1;
-    a.A = (const void*)256; a.B = (const void*)256; a.C = (void*)256;  // alignment probes only
-    p->s_nt_bytes = hct_gemm_workspace_bytes(&a);
+    p->s_nt_bytes = hct_gemm_nt_stream_k_bytes();
     w.take(p->s_nt_bytes);
   }
   size_t gw = 0;
@@ -845,20 +841,20 @@ int hct_vit_backward_stage(hct_mae_plan* p, int stage, const void* dlatent, void
     RC(hct_layernorm_bwd(dlatent, p->dt, (const float*)(ws + p->h_enc[ne]), (const float*)(ws + p->a_lat_mean), (const float*)(ws + p->a_lat_rstd),
                          p->pf(p->p_norm_w), nullptr, p->Me, p->D, dh, ws + enc_out(ne - 1), p->dt, p->gf(p->p_norm_w), p->gf(p->p_norm_b),
                          ne > 0 ? p->gf(p->enc[ne - 1].fc2_b) : nullptr, small, p->s_small_bytes, s));
-    return end_stage(p, stage, false, false, Re, s);
+    return end_stage(p, stage, false, false, Re, ne, s);
   }
   if (stage <= ne) {
     const int i = ne - stage;
     RC(block_backward(p, p->enc[i], p->aenc[i], p->genc[i % Re], enc_out(i - 1), (const float*)(ws + p->h_enc[i]), B, p->Ne, p->D, p->Mlp, p->H,
                       i > 0 ? p->enc[i - 1].fc2_b : -1, s));
-    return end_stage(p, stage, true, false, Re, s);
+    return end_stage(p, stage, true, false, Re, ne, s);
   }
   if (stage == ne + 1) {  // input assembly -> patch embedding
     void* dtok = ws + p->a_dtok;
     RC(hct_vit_assemble_bwd(dh, B, p->L, p->R, p->D, dtok, p->dt, p->gf(p->p_cls), p->p_reg >= 0 ? p->gf(p->p_reg) : nullptr,
                             p->p_pos >= 0 ? p->gf(p->p_pos) : nullptr, s));
     RC(linear_wgrad(p, dtok, ws + p->a_patches, B * p->L, p->D, p->pd, p->p_pe_w, p->p_pe_b, s));
-    return end_stage(p, stage, false, false, Re, s);
+    return end_stage(p, stage, false, false, Re, ne, s);
   }
   set_error("hct_vit_backward_stage: stage %d out of range", stage);
   return HCT_E_BADARG;
@@ -911,7 +907,7 @@ int hct_mae_backward_stage(hct_mae_plan* p, int stage, void* stream) {
     RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + p->h_dec[nd]), (const float*)(ws + p->a_yn_mean), (const float*)(ws + p->a_yn_rstd),
                          p->pf(p->p_dnorm_w), nullptr, Mt, p->Dd, dht, dhs, p->dt, p->gf(p->p_dnorm_w), p->gf(p->p_dnorm_b),
                          nd > 0 ? p->gf(p->dec[nd - 1].fc2_b) : nullptr, small, p->s_small_bytes, s));
-    return end_stage(p, stage, false, nd == 0, Rd, s);
+    return end_stage(p, stage, false, nd == 0, Rd, nd, s);
   }
   if (stage <= nd) {
     const int i = nd - stage;
@@ -920,7 +916,7 @@ int hct_mae_backward_stage(hct_mae_plan* p, int stage, void* stream) {
     else
       RC(block_backward(p, p->dec[i], p->adec[i], p->gdec[i % Rd], dec_out(i - 1), (const float*)(ws + p->h_dec[i]), B, p->Nd, p->Dd, p->Mlpd, p->Hd,
                         i > 0 ? p->dec[i - 1].fc2_b : -1, s));
-    return end_stage(p, stage, true, stage == nd, Rd, s);  // (the decoder's products run together once its backward is through)
+    return end_stage(p, stage, true, stage == nd, Rd, nd, s);  // (the decoder's products run together once its backward is through)
   }
   if (stage == nd + 1) {  // decoder input assembly -> decoder_embed -> encoder norm
     void* de = ws + p->a_de;
@@ -932,20 +928,20 @@ int hct_mae_backward_stage(hct_mae_plan* p, int stage, void* stream) {
     RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + p->h_enc[ne]), (const float*)(ws + p->a_lat_mean), (const float*)(ws + p->a_lat_rstd),
                          p->pf(p->p_norm_w), nullptr, p->Me, p->D, dh, dhs, p->dt, p->gf(p->p_norm_w), p->gf(p->p_norm_b),
                          ne > 0 ? p->gf(p->enc[ne - 1].fc2_b) : nullptr, small, p->s_small_bytes, s));
-    return end_stage(p, stage, false, false, Re, s);
+    return end_stage(p, stage, false, false, Re, ne, s);
   }
   if (stage <= nd + 1 + ne) {
     const int i = ne - (stage - nd - 1);
     RC(block_backward(p, p->enc[i], p->aenc[i], p->genc[i % Re], enc_out(i - 1), (const float*)(ws + p->h_enc[i]), B, p->Ne, p->D, p->Mlp, p->H,
                       i > 0 ? p->enc[i - 1].fc2_b : -1, s));
-    return end_stage(p, stage, true, false, Re, s);
+    return end_stage(p, stage, true, false, Re, ne, s);
   }
   if (stage == nd + ne + 2) {  // encoder input assembly -> patch embedding
     void* dtok = ws + p->a_dtok;
     RC(hct_encoder_assemble_bwd(dh, (const int32_t*)(ws + p->a_ids_restore), B, p->L, p->K, p->D, dtok, p->dt, p->gf(p->p_cls),
                                 p->p_pos >= 0 ? p->gf(p->p_pos) : nullptr, small, p->s_small_bytes, s));
     RC(linear_wgrad(p, dtok, ws + p->a_patches, B * p->K, p->D, p->pd, p->p_pe_w, p->p_pe_b, s));
-    return end_stage(p, stage, false, false, Re, s);
+    return end_stage(p, stage, false, false, Re, ne, s);
   }
   set_error("hct_mae_backward_stage: stage %d out of range", stage);
   return HCT_E_BADARG;

@@ -123,7 +123,7 @@ class DinoOptimizer:
     """AdamW over the student's two flat parameter buffers (backbone plan + projection head): two fused HipAdamW launches that
     share the learning rate and weight decay of `param_groups[0]` (what the LR scheduler and the weight-decay schedule write to).
     The reference builds one torch AdamW over MultiCropWrapper.parameters() (main_pretrain_dino.py:219); the arithmetic per
-    parameter is the same, the state dict is split in two ({'backbone': ..., 'head': ...})."""
+    parameter is the same, and `state_dict()` has the reference's flat layout (one AdamW state dict over backbone + head parameters)."""
 
     def __init__(self, model, lr, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8):
         from .optim import HipAdamW
@@ -145,12 +145,35 @@ class DinoOptimizer:
         self.primary.step()
         self.secondary.step()
 
+    # The checkpoint's "optimizer" entry has the reference's layout: ONE torch AdamW state dict over MultiCropWrapper.parameters()
+    # (main_pretrain_dino.py:219; misc.py:55-69 loads it back), i.e. state indices 0 .. nb-1 = backbone parameters, nb .. = head
+    # parameters, one param group.  The two fused optimizers' dicts are merged / split at nb.
+    def _nb(self) -> int:
+        return len(self.primary.param_groups[0]["params"])
+
     def state_dict(self):
-        return {"backbone": self.primary.state_dict(), "head": self.secondary.state_dict()}
+        a, b = self.primary.state_dict(), self.secondary.state_dict()
+        nb = len(a["param_groups"][0]["params"])
+        state = dict(a["state"])
+        state.update({nb + i: v for i, v in b["state"].items()})
+        group = dict(a["param_groups"][0])
+        group["params"] = list(range(nb + len(b["param_groups"][0]["params"])))
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.primary.load_state_dict(sd["backbone"])
-        self.secondary.load_state_dict(sd["head"])
+        if "backbone" in sd and "head" in sd:  # checkpoints written before the flat layout
+            self.primary.load_state_dict(sd["backbone"])
+            self.secondary.load_state_dict(sd["head"])
+            return
+        nb, nh = self._nb(), len(self.secondary.param_groups[0]["params"])
+        group = sd["param_groups"][0]
+        if len(sd["param_groups"]) != 1 or len(group["params"]) != nb + nh:
+            raise ValueError(f"optimizer state of {sum(len(g['params']) for g in sd['param_groups'])} parameters in {len(sd['param_groups'])} "
+                             f"group(s) does not match backbone ({nb}) + head ({nh}) in one group")
+        ga, gb = dict(group), dict(group)
+        ga["params"], gb["params"] = list(range(nb)), list(range(nh))
+        self.primary.load_state_dict({"state": {i: v for i, v in sd["state"].items() if i < nb}, "param_groups": [ga]})
+        self.secondary.load_state_dict({"state": {i - nb: v for i, v in sd["state"].items() if i >= nb}, "param_groups": [gb]})
 
 
 class DinoDataParallel(nn.Module):

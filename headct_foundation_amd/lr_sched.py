@@ -11,20 +11,21 @@ import math
 from torch.optim.lr_scheduler import LambdaLR
 
 
-class WarmupCosine:
-    """Multiplicative factor lr(step) / lr0.  A callable object rather than a closure: LambdaLR stores its attributes
-    (five numbers) in `state_dict()["lr_lambdas"]`; a reference checkpoint holds `[None]` there, which LambdaLR skips."""
+def warmup_cosine(lr0: float, lr_end: float, warmup: int, total: int, cycles: float):
+    """Multiplicative factor lr(step) / lr0 as a plain closure: LambdaLR.state_dict() stores `None` for functions (only callable
+    OBJECTS have their attributes saved), exactly what a reference checkpoint holds under scheduler["lr_lambdas"] -- so a resume
+    with a changed MAX_EPOCHS / PER_WARMUP / LR follows the NEW run's curve, as the reference's does, instead of silently
+    restoring the old one's constants."""
+    lr0, lr_end, warmup, total, cycles = float(lr0), float(lr_end), int(warmup), int(total), float(cycles)
 
-    def __init__(self, lr0: float, lr_end: float, warmup: int, total: int, cycles: float):
-        self.lr0, self.lr_end = float(lr0), float(lr_end)
-        self.warmup, self.total, self.cycles = int(warmup), int(total), float(cycles)
+    def factor(step: int) -> float:
+        if step < warmup:
+            return step / max(1, warmup)
+        done = (step - warmup) / max(1, total - warmup)
+        wave = 0.5 * (1.0 + math.cos(2.0 * math.pi * cycles * done))
+        return max(0.0, (lr_end + (lr0 - lr_end) * wave) / lr0)
 
-    def __call__(self, step: int) -> float:
-        if step < self.warmup:
-            return step / max(1, self.warmup)
-        done = (step - self.warmup) / max(1, self.total - self.warmup)
-        wave = 0.5 * (1.0 + math.cos(2.0 * math.pi * self.cycles * done))
-        return max(0.0, (self.lr_end + (self.lr0 - self.lr_end) * wave) / self.lr0)
+    return factor
 
 
 def get_cosine_schedule_with_warmup(optimizer, num_warmup_steps: int, num_training_steps: int, num_cycles: float = 0.5,
@@ -32,7 +33,7 @@ def get_cosine_schedule_with_warmup(optimizer, num_warmup_steps: int, num_traini
     lr0 = optimizer.defaults["lr"]
     if lr_end >= lr0:
         raise ValueError(f"cosine schedule needs lr_end < initial lr, got lr_end={lr_end} and lr={lr0}")
-    return LambdaLR(optimizer, WarmupCosine(lr0, lr_end, num_warmup_steps, num_training_steps, num_cycles), last_epoch)
+    return LambdaLR(optimizer, warmup_cosine(lr0, lr_end, num_warmup_steps, num_training_steps, num_cycles), last_epoch)
 
 
 def get_lr_scheduler(config, optimizer, num_warmup_steps, total_steps, min_lr):

@@ -83,13 +83,16 @@ size_t hct_gemm_workspace_bytes(const hct_gemm_args* a);
 /* NT path (forward Linears / dgrads), persistent 256x256 kernel: when the tile count leaves a partly filled last round, the
  * remainder tiles are shared out by K range over all CUs ("stream-K"; whole tiles for the rest), partial accumulators passing
  * through the LAST 64 MiB + 4 KiB of `workspace` in a fixed summation order (bit-reproducible).  Optional: with a smaller (or
- * no) workspace the launch uses whole tiles only.  hct_gemm_nt_flags_offset = byte offset of that region's head inside a
+ * no) workspace the launch uses whole tiles only.  hct_gemm_workspace_bytes includes the region only for shapes whose
+ * remainder round would be shared out on the present CU count.  An owner that waits in vain for a partial (a grid that is
+ * not wholly resident) sets the error word AND fills its tile with NaN.  hct_gemm_nt_flags_offset = byte offset of that region's head inside a
  * workspace of the given size ((size_t)-1: too small): 256 32-bit arrival flags, and at byte 2048 an error word that a launch
  * sets to 0xDEAD if a partial never arrived (cannot happen while the grid is resident; it is flagged rather than waited for).
  * The head is reset before every such launch unless `workspace_armed` says that it started zeroed and only hct_gemm has
  * written it since.  Environment: HCT_NT_STREAMK_PAIRS = least number of K-stage pairs per CU the sharing must save for it
  * to be used (default 20, tuned on the MAE step; a huge value switches it off). */
 size_t hct_gemm_nt_flags_offset(size_t workspace_bytes);
+size_t hct_gemm_nt_stream_k_bytes(void); /* size of that region: what a caller that keeps ONE workspace for many shapes appends to it */
 /* Leave `n` CUs out of the persistent GEMM grids (default 0) so that communication kernels (RCCL all-reduce overlapped
  * with the backward) have somewhere to run; set by the data-parallel wrapper when world_size > 1. */
 void hct_set_cu_reserve(int n);

@@ -36,8 +36,19 @@ HOOKS = {
     # on = stream-K where it saves >= 20 / 16 stage pairs per CU, off = whole tiles only
     "sk20": (lambda: (lib.hct_debug_set_gemm_variant(-1000 - 512), lib.hct_debug_set_gemm_variant(-100 - 20)), lambda: lib.hct_debug_set_gemm_variant(-1000 - (1 << 24))),
     "sk16": (lambda: (lib.hct_debug_set_gemm_variant(-1000 - 512), lib.hct_debug_set_gemm_variant(-100 - 16)), lambda: lib.hct_debug_set_gemm_variant(-1000 - (1 << 24))),
+    # on = weight gradients queued and run in grouped launches (the default), off = every weight gradient inside its stage (split-K + fold)
+    "wgdefer": (lambda: [lib.hct_mae_plan_set_wgrad_defer(pl.handle, 1, 0) for pl in model._plans.values()],
+                lambda: [lib.hct_mae_plan_set_wgrad_defer(pl.handle, 0, 0) for pl in model._plans.values()]),
+    "wggroup4": (lambda: [lib.hct_mae_plan_set_wgrad_defer(pl.handle, 1, 4) for pl in model._plans.values()],
+                 lambda: [lib.hct_mae_plan_set_wgrad_defer(pl.handle, 1, 0) for pl in model._plans.values()]),
+    # on = the module default (decoder tail on the masked patches' rows only), off = every row through the whole decoder
+    "tail": (lambda: setattr(model, "full_pred", False), lambda: setattr(model, "full_pred", True)),
+    # on = the persistent GEMM grids of the BACKWARD leave 16 CUs free (what the data-parallel wrapper does while gradient buckets are
+    # in flight, ddp.py): its cost at world size 1 is the floor of the scaling loss
+    "reserve16": (lambda: globals().__setitem__("BWD_RESERVE", 16), lambda: globals().__setitem__("BWD_RESERVE", 0)),
     "none": (lambda: None, lambda: None),
 }
+BWD_RESERVE = 0
 name = sys.argv[1] if len(sys.argv) > 1 else "none"
 on, off = HOOKS[name]
 dev = torch.device("cuda", 0)
@@ -56,7 +67,11 @@ def block(n):
     for i in range(n):
         opt.zero_grad()
         loss, _, _ = model(pool[i % 2], noise=noises[i % 2])
+        if BWD_RESERVE:
+            lib.hct_set_cu_reserve(BWD_RESERVE)
         loss.backward()
+        if BWD_RESERVE:
+            lib.hct_set_cu_reserve(0)
         clip_gradients(model, 3.0)
         opt.step(); sched.step()
     torch.cuda.synchronize()

@@ -13,6 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -111,3 +112,23 @@ def test_two_ranks_one_card(cuda, dtype, cap_mb):
     assert nb >= 1
     if cap_mb < 1e-6:
         assert nb > 3  # one bucket per backward stage with a zero cap
+
+
+def test_bench_two_ranks_rehearsal(cuda):
+    """The N > 1 path of bench.py itself (rendezvous, per-rank seeds, barrier + synchronize fences, MAX-reduce of the elapsed time, one
+    JSON line from rank 0): `--gpus 2` launched the way the driver launches it, with HCT_BENCH_REHEARSAL=1 putting both ranks on this
+    one card over gloo (the driver's runs use one rank per GPU over RCCL).  Small batch: only the code path is under test."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=ROOT, HCT_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["config"]["global_batch"] == 16
+    assert out["config"]["parallelism"] == "dp2" and out["value"] > 0 and abs(out["value"] - 16 * 1e3 / out["ms_per_step"]) < 0.01 * out["value"]
+    assert "cpu_baseline" not in out and out["roofline"] is not None

@@ -35,6 +35,51 @@ def test_main_pretrain_mae_plumbing_run(cuda, tmp_path):
     assert set(st[0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(st[0]["step"]) == 8.0  # 4 it/epoch x 2
 
 
+def test_async_loss_readback_logs_what_the_synchronous_loop_logs(lib, cuda, monkeypatch):
+    """train_one_epoch reads the loss back one iteration late through a pinned buffer (no per-iteration device synchronisation);
+    HCT_SYNC_LOSS=1 is the reference's synchronize + .item() per iteration (engine_pretrain_mae.py:73-74).  Same log lines in the
+    same order, same epoch statistics (fp32 path: bit-identical runs)."""
+    import engine_pretrain_mae as E
+    from oracle import mae_oracle as O
+    from headct_foundation_amd import MaskedAutoencoderViT
+    from headct_foundation_amd.cfgnode import CfgNode
+    from headct_foundation_amd.lr_sched import get_cosine_schedule_with_warmup
+    from headct_foundation_amd.optim import HipAdamW
+    cfg = O.CONFIGS["micro"]
+    ecfg = CfgNode()
+    ecfg.MODEL = CfgNode(); ecfg.MODEL.NAME = "mae"
+    ecfg.TRAIN = CfgNode(); ecfg.TRAIN.GRAD_CLIP = 3.0
+
+    class Lines(logging.Handler):
+        def __init__(self):
+            super().__init__()
+            self.lines = []
+
+        def emit(self, record):
+            self.lines.append(record.getMessage())
+
+    def run(sync):
+        monkeypatch.setenv("HCT_SYNC_LOSS", "1" if sync else "0")
+        torch.manual_seed(0)
+        m = MaskedAutoencoderViT(**cfg.ctor_kwargs(), compute_dtype="fp32")
+        m.load_state_dict(O.make_params(cfg, 0))
+        m = m.to(cuda)
+        opt = HipAdamW(m, lr=1e-3, weight_decay=5e-3, betas=(0.9, 0.95))
+        sch = get_cosine_schedule_with_warmup(opt, 2, 10, lr_end=1e-6)
+        batches = [O.make_volume(cfg, 2, 30 + i) for i in range(5)]
+        log = logging.getLogger(f"tap{int(sync)}")
+        log.setLevel(logging.INFO); log.propagate = False
+        h = Lines(); log.addHandler(h)
+        torch.manual_seed(123)  # the masking noise is drawn inside forward
+        stats = E.train_one_epoch(ecfg, m, batches, opt, sch, 0, 1, logger=log, device=cuda)
+        return h.lines, stats
+
+    a_lines, a_stats = run(False)
+    s_lines, s_stats = run(True)
+    assert len(a_lines) == 6 and a_lines == s_lines  # 5 iteration lines + "Averaged stats"
+    assert a_stats == s_stats and set(a_stats) == {"loss", "lr"}
+
+
 def test_resume_reproduces_uninterrupted_run(lib, cuda, tmp_path):
     """save_checkpoint -> new model/optimizer -> load -> continue == uninterrupted training (bit-exact fp32 path)."""
     from oracle import mae_oracle as O

@@ -31,9 +31,10 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_gemm_workspace_sizes_host_side(lib):
-    """hct_gemm_workspace_bytes / hct_gemm_nt_flags_offset are host arithmetic (no device call): a forward / dgrad product of
-    K >= 512 asks for the stream-K region (64 MiB of slabs + a 4 KiB head) behind its column-sum partials, shorter K does not,
-    and the flags sit at a 256-byte aligned offset from the END of whatever workspace is passed."""
+    """hct_gemm_workspace_bytes / hct_gemm_nt_flags_offset are host arithmetic (no device call): a forward / dgrad product whose
+    remainder round of tiles would be shared out by K range (K >= 512, enough stage pairs to gain) asks for the stream-K region
+    (64 MiB of slabs + a 4 KiB head) behind its column-sum partials, other shapes do not, and the flags sit at a 256-byte aligned
+    offset from the END of whatever workspace is passed."""
     from headct_foundation_amd._lib import HCT_BF16, GemmArgs
     sk = 256 * 262144 + 4096
 
@@ -48,10 +49,12 @@ def test_gemm_workspace_sizes_host_side(lib):
             a.colsum_out = 256
         return lib.hct_gemm_workspace_bytes(C.byref(a))
 
-    assert nt(55552, 768, 3072) == sk and nt(1000, 768, 512) == sk
+    assert lib.hct_gemm_nt_stream_k_bytes() == sk
+    assert nt(55552, 768, 3072) == sk  # 651 tiles on 256 CUs (no GPU here: the library assumes 256): 139 remainder tiles, 22 pairs saved
+    assert nt(1000, 768, 512) == 0 and nt(14080, 768, 3072) == 0  # too little to gain (threshold: 20 stage pairs per CU)
     assert nt(55552, 3072, 256) == 0 and nt(55552, 768, 448) == 0  # K < 512, or not a multiple of 64 on the persistent kernel
     with_cs = nt(55552, 3072, 768, colsum=True)
-    assert with_cs > sk and (with_cs - sk) % 256 == 0 and with_cs - sk >= 217 * 4 * 3072 * 4
+    assert with_cs >= 217 * 4 * 3072 * 4 and with_cs < sk  # column-sum partials only: 2604 tiles leave too short a remainder
     none = 2 ** 64 - 1
     assert lib.hct_gemm_nt_flags_offset(0) == none and lib.hct_gemm_nt_flags_offset(sk - 1) == none
     assert lib.hct_gemm_nt_flags_offset(sk) == 0
@@ -114,6 +117,72 @@ def test_forward_fails_loudly_without_gpu(lib):
     opt = HipAdamW(m, lr=1e-3)
     with pytest.raises(HctError):
         opt.step()
+
+
+def test_lr_scheduler_resume_follows_the_new_run(lib):
+    """LambdaLR saves the attributes of a callable OBJECT and restores them on load; a closure is saved as None, which is what a
+    reference checkpoint holds (lr_sched.py:127-139 builds a closure): a resume with another total / warm-up / final rate then
+    follows the NEW curve from the restored step count (the base rate itself is part of LambdaLR's saved state, `base_lrs`, in the
+    reference as here)."""
+    from headct_foundation_amd.lr_sched import get_cosine_schedule_with_warmup
+    mk = lambda lr: torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=lr)
+    old_opt = mk(1e-3)
+    old = get_cosine_schedule_with_warmup(old_opt, 5, 100, lr_end=1e-6)
+    for _ in range(20):
+        old_opt.step(); old.step()
+    sd = old.state_dict()
+    assert sd["lr_lambdas"] == [None]
+    new_opt = mk(1e-3)
+    new = get_cosine_schedule_with_warmup(new_opt, 10, 400, lr_end=2e-6)
+    new.load_state_dict(sd)
+    fresh_opt = mk(1e-3)
+    fresh = get_cosine_schedule_with_warmup(fresh_opt, 10, 400, lr_end=2e-6)
+    for _ in range(20):
+        fresh_opt.step(); fresh.step()
+    for _ in range(30):
+        new_opt.step(); new.step(); fresh_opt.step(); fresh.step()
+        assert abs(new_opt.param_groups[0]["lr"] - fresh_opt.param_groups[0]["lr"]) < 1e-15
+
+
+def test_dino_optimizer_state_dict_has_the_reference_layout():
+    """DinoOptimizer.state_dict() merges / splits the two fused optimizers' dicts at the number of backbone parameters: the result is
+    what ONE torch.optim.AdamW over [backbone parameters, head parameters] carries (main_pretrain_dino.py:219), so reference DINO
+    checkpoints load and ours are readable by the reference's load_optimizer (misc.py:55-69).  Host logic only: stand-ins for the
+    two fused optimizers."""
+    from headct_foundation_amd.dino import DinoOptimizer
+
+    class _Half:
+        def __init__(self, n, base):
+            self.param_groups = [{"lr": 0.1, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0.04, "params": list(range(n))}]
+            self.state = {i: {"step": torch.tensor(3.0), "exp_avg": torch.full((2,), float(base + i)), "exp_avg_sq": torch.zeros(2)} for i in range(n)}
+
+        def state_dict(self):
+            return {"state": dict(self.state), "param_groups": [dict(self.param_groups[0])]}
+
+        def load_state_dict(self, sd):
+            self.loaded = sd
+
+    opt = DinoOptimizer.__new__(DinoOptimizer)
+    opt.primary, opt.secondary = _Half(5, 0), _Half(3, 100)
+    sd = opt.state_dict()
+    assert sorted(sd["state"]) == list(range(8)) and len(sd["param_groups"]) == 1 and sd["param_groups"][0]["params"] == list(range(8))
+    assert float(sd["state"][5]["exp_avg"][0]) == 100.0 and float(sd["state"][4]["exp_avg"][0]) == 4.0
+    # the same layout as torch.optim.AdamW over the concatenated parameter list
+    ps = [torch.nn.Parameter(torch.zeros(2)) for _ in range(8)]
+    ref = torch.optim.AdamW(ps, lr=0.1, weight_decay=0.04)
+    for p in ps:
+        p.grad = torch.ones(2)
+    ref.step()
+    rsd = ref.state_dict()
+    assert sorted(rsd["state"]) == sorted(sd["state"]) and rsd["param_groups"][0]["params"] == sd["param_groups"][0]["params"]
+    assert set(rsd["state"][0]) == set(sd["state"][0])
+    opt.load_state_dict(rsd)  # a reference-style dict splits at 5
+    assert sorted(opt.primary.loaded["state"]) == list(range(5)) and sorted(opt.secondary.loaded["state"]) == list(range(3))
+    assert opt.primary.loaded["param_groups"][0]["params"] == list(range(5)) and opt.secondary.loaded["param_groups"][0]["params"] == list(range(3))
+    opt.load_state_dict({"backbone": {"x": 1}, "head": {"y": 2}})  # the split form of older checkpoints still loads
+    assert opt.primary.loaded == {"x": 1} and opt.secondary.loaded == {"y": 2}
+    with pytest.raises(ValueError):
+        opt.load_state_dict({"state": {}, "param_groups": [{"params": list(range(7))}]})
 
 
 def test_lr_scheduler_matches_reference_values(lib):

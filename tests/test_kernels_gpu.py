@@ -170,6 +170,37 @@ def test_gemm_nt_stream_k_remainder(lib, cuda, M, N, K, reserve):
     assert rel_err(sk["cs"], whole["cs"]) < 1e-4
 
 
+def test_stream_k_timeout_poisons_the_output(lib, cuda):
+    """A stream-K partial that never arrives (a grid that is not wholly resident, e.g. beside a communication kernel that holds
+    more CUs than were reserved for it) must not produce silently wrong numbers: the owner of the shared tile sets the error word
+    AND poisons its tile with NaN, which the engine's finite-loss check catches.  The debug hook -8 makes every follower publish a
+    wrong sequence number; -9 restores it, after which the same call is finite and correct again.  NT kernel and grouped wgrad."""
+    M, N, K = 2048, 2048, 1024
+    A = _rand((M, K), cuda, torch.bfloat16, 11)
+    B = _rand((N, K), cuda, torch.bfloat16, 12, 0.05)
+    ws = torch.zeros((1 << 20) + 64 * 1024 * 1024 + 4096, dtype=torch.uint8, device=cuda)
+    flags = ws[lib.hct_gemm_nt_flags_offset(ws.numel()):][:4096].view(torch.int32)
+    ops = [(_rand((2000, 768), cuda, torch.bfloat16, 21), _rand((2000, 512), cuda, torch.bfloat16, 22, 0.1), 1.0)]
+    lib.hct_debug_set_gemm_variant(-100 - 1)
+    try:
+        lib.hct_debug_set_gemm_variant(-8)
+        bad = _nt_call(lib, A, B, M, N, K, ws, torch.float32)
+        torch.cuda.synchronize()
+        assert int(flags[512]) == 0xDEAD and torch.isnan(bad).any() and not torch.isnan(bad).all()
+        with pytest.raises(AssertionError):
+            _tn_group(lib, ops)  # (its own check of the error word)
+        lib.hct_debug_set_gemm_variant(-9)
+        flags.zero_()
+        good = _nt_call(lib, A, B, M, N, K, ws, torch.float32)
+        torch.cuda.synchronize()
+        assert int(flags[512]) == 0 and rel_err(good, A.float() @ B.float().t()) < 1e-5
+        (g,) = _tn_group(lib, ops)
+        assert rel_err(g, ops[0][0].float().t() @ ops[0][1].float()) < 2e-5
+    finally:
+        lib.hct_debug_set_gemm_variant(-9)
+        lib.hct_debug_set_gemm_variant(-100 - 20)
+
+
 @pytest.mark.parametrize("R,M,N", [(217 * 4, 768, 768), (55 * 5, 2304, 768), (1000, 768, 3072), (64, 192, 192),
                                    (5000, 4096, 768), (33, 48, 64), (130, 576, 192)])
 def test_gemm_tn_bf16_mfma(lib, cuda, R, M, N):
@@ -216,6 +247,8 @@ def _tn_group(lib, ops, reps=1):
         _lib.check(lib.hct_gemm_tn_group_run(C.cast(jobs, C.c_void_p), n, ws.data_ptr(), nbytes, _st()), "tn_group_run")
     torch.cuda.synchronize()
     flags = ws[lib.hct_gemm_tn_group_workspace_bytes(n) - (256 * 262144 + 4096):][:4096].view(torch.int32)
+    if int(flags[512]) != 0:  # a partial never arrived: the owners' tiles must then be NaN, not silently wrong
+        assert any(torch.isnan(o).any() for o in outs)
     assert int(flags[512]) == 0, "a stream-K partial of the grouped wgrad never arrived"
     return outs
 
