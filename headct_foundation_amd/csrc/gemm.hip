@@ -26,6 +26,7 @@ static int g_stagger = -1;  // -1 auto, >= 0 forced (testing)
 static int g_tn_separate_fold = 1;  // 1 = split partials folded by gemm_fold_kernel; 0 = inside the wgrad launch (measured 0.36 ms per step SLOWER:
                                      // DESIGN.md section 5; kept selectable and tested, -6 / -7 of hct_debug_set_gemm_variant)
 static int g_nt_variant = 0;  // 0 auto; 128 / 256 / 4 force one NT kernel (tests cover every instance)
+static int g_w4_small = 0;    // testing (-10 / -11): the two-workgroups-per-CU variant for single-round shapes (tiles < CUs < 2 x tiles)
 static int g_sk_drop = 0;     // testing (hct_debug_set_gemm_variant(-8 / -9)): stream-K followers publish a wrong sequence number -> every owner times out
 
 struct Epilogue {
@@ -2314,6 +2315,7 @@ void hct_set_cu_reserve(int n) { g_cu_reserve = n < 0 ? 0 : n; }
 void hct_debug_set_gemm_variant(int v) {
   if (v == -4 || v == -5) { g_w4_auto = v == -4; return; }
   if (v == -8 || v == -9) { g_sk_drop = v == -8; return; }
+  if (v == -10 || v == -11) { g_w4_small = v == -10; return; }
   if (v <= -1000) { g_sk_min_k = -v - 1000; return; }       // stream-K of the NT remainder round only for K >= this (huge: off)
   if (v <= -100) { g_sk_gain_pairs = -v - 100; return; }     // ... and only where it saves at least this many stage pairs per CU
   if (v == -6 || v == -7) { g_tn_separate_fold = v == -6; return; }  // -6 / -7: separate fold kernel for the wgrad splits on / off  // -4 / -5: auto-dispatch of the 2-WG/CU variant on / off
@@ -2503,7 +2505,8 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
       // +residual: fp32 read + write), K is short and there are several tiles per CU
       const bool w4_shape = a->K <= 1024 && ((mode == EPI_GELU_BF16 && tiles256 >= 4 * num_cus()) ||
                                              (mode == EPI_RES_F32 && tiles256 >= 2 * num_cus()));
-      const bool w4 = (g_nt_variant == 4) || (g_nt_variant == 0 && g_w4_auto && w4_shape);
+      const bool w4_small = g_w4_small && tiles256 < num_cus() && 2 * tiles256 > num_cus() && mode != EPI_GENERIC && !a->colsum_out;
+      const bool w4 = (g_nt_variant == 4) || (g_nt_variant == 0 && ((g_w4_auto && w4_shape) || w4_small));
       if (w4) {
         const int tiles = ((a->M + 255) / 256) * ((a->N + 127) / 128);
         const dim3 g4(std::min(tiles, 2 * num_cus()));

@@ -46,6 +46,12 @@ HOOKS = {
     # on = the persistent GEMM grids of the BACKWARD leave 16 CUs free (what the data-parallel wrapper does while gradient buckets are
     # in flight, ddp.py): its cost at world size 1 is the floor of the scaling loss
     "reserve16": (lambda: globals().__setitem__("BWD_RESERVE", 16), lambda: globals().__setitem__("BWD_RESERVE", 0)),
+    "wggroup6": (lambda: [lib.hct_mae_plan_set_wgrad_defer(pl.handle, 1, 6) for pl in model._plans.values()],
+                 lambda: [lib.hct_mae_plan_set_wgrad_defer(pl.handle, 1, 0) for pl in model._plans.values()]),
+    # on = two workgroups per CU (256 x 128 tiles) for the shapes with less than one round of 256 x 256 tiles (the encoder's 165)
+    "w4small": (lambda: lib.hct_debug_set_gemm_variant(-10), lambda: lib.hct_debug_set_gemm_variant(-11)),
+    "skgain12": (lambda: lib.hct_debug_set_gemm_variant(-100 - 12), lambda: lib.hct_debug_set_gemm_variant(-100 - 20)),
+    "skgain16": (lambda: lib.hct_debug_set_gemm_variant(-100 - 16), lambda: lib.hct_debug_set_gemm_variant(-100 - 20)),
     "none": (lambda: None, lambda: None),
 }
 BWD_RESERVE = 0

@@ -186,7 +186,7 @@ def test_stream_k_timeout_poisons_the_output(lib, cuda):
         lib.hct_debug_set_gemm_variant(-8)
         bad = _nt_call(lib, A, B, M, N, K, ws, torch.float32)
         torch.cuda.synchronize()
-        assert int(flags[512]) == 0xDEAD and torch.isnan(bad).any() and not torch.isnan(bad).all()
+        assert int(flags[512]) == 0xDEAD and torch.isnan(bad).all()  # (64 tiles on 256 CUs: every tile is shared, every owner timed out)
         with pytest.raises(AssertionError):
             _tn_group(lib, ops)  # (its own check of the error word)
         lib.hct_debug_set_gemm_variant(-9)
