@@ -1746,60 +1746,83 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn256_kernel(int M, int N, i
 // wgrads of several blocks and runs them here together.  With enough output tiles to fill the chip there is no need to split the
 // reduction: no fp32 partial slabs (65 MB per product before), no fold launch, one prologue / epilogue per 256x256 tile of the
 // FULL reduction instead of one per split, two launches per step instead of 166.
-//   tiles    : listed job-major, tile t of a job = (t / ntn, t % ntn); T tiles in all, G = grid = #CUs.
+//   tiles    : T tiles in all, listed as SEGMENTS (job, first tile, count) that the host orders so that a window of 32 consecutive
+//              tile ids is, where it can be, 32 tiles of ONE product (tn_group_segments); tile t of a job = (t / ntn, t % ntn);
+//              G = grid = #CUs.
 //   rounds   : the first F = T / G rounds are whole tiles; workgroup c takes tile r * G + q(c) in round r, q(c) = (c & 7) * G/8 +
-//              (c >> 3): the 32 workgroups of an XCD (dealt round-robin) sweep the reduction rows of 32 consecutive tiles -- mostly
-//              ONE product -- together, so its A / B row panels are fetched once per XCD (as the splits of one product were before).
-//   remainder: the last T - F * G tiles are shared out by reduction range ("stream-K"): their stages (32 rows each, a multiple of
-//              4 per tile) form one sequence of S stages, cut into W contiguous ranges at multiples of 4; a range is split at tile
-//              boundaries into at most one FOLLOWER piece (starts inside a tile: raw accumulators to slab q, then flag q) and
-//              whole / OWNER pieces (start a tile; an owner adds the slabs of the workgroups that continue its tile, in order
-//              q+1, q+2, ... -- fixed order, bit-reproducible -- and runs the epilogue).  The follower piece is the first thing a
-//              workgroup does in the remainder phase and never waits: no cycles.  A bounded spin poisons the tile with NaN (the
-//              engine's finite-loss check then stops the run) instead of hanging should the grid not be resident.
+//              (c >> 3): the 32 workgroups of an XCD (dealt round-robin) sweep the reduction rows of one window together, so the
+//              A / B row panels of its product are fetched once per XCD (3 + 12 panels for 32 tiles of a 768 x 3072 gradient;
+//              the kernel draws 4.4 TB/s as it is -- windows that mix two products measured 9 % slower).
+//   remainder: the last Rm = T - F * G tiles are split over the reduction into `ns_split` pieces each (units of 4 stages, dealt
+//              evenly), chosen on the host so that Rm * ns_split fills whole rounds; piece p = split * Rm + tile, workgroup q takes
+//              pieces q, q + G, ...: a window of 32 consecutive pieces is the SAME reduction range of 32 consecutive tiles, shared
+//              through L2 like a whole-tile window (contiguous per-workgroup stage ranges -- the first form of this kernel -- left
+//              every workgroup streaming panels of its own: 25 % slower).  Pieces of splits 0 .. ns_split-2 are FOLLOWERS (raw
+//              accumulators to slab p, then flag p); the LAST split's piece OWNS the tile: it adds the slabs in split order (fixed:
+//              bit-reproducible) and runs the epilogue.  Every workgroup meets its follower pieces before its owner pieces and a
+//              follower never waits: no cycles.  A bounded spin poisons the tile with NaN (the engine's finite-loss check then
+//              stops the run) instead of hanging should the grid not be resident.
 struct TnJob {                 // 80 bytes, device copy written by tn_group_table_kernel
   const bf16* A; const bf16* B; float* C;
   int M, N, R, lda, ldb, ldc;
-  int tile0, ntiles, ntn, nk;  // first tile id, tiles, column tiles, stages per tile (R / 32 rounded up to a multiple of 4)
+  int tile0, ntiles, ntn, nk;  // (tile0 unused by the kernel), tiles, column tiles, stages per tile (R / 32 rounded up to a multiple of 4)
   float alpha; int pad[3];
 };
+struct TnSeg { int job, tile_first, count, gtile0; };  // tiles [tile_first, tile_first + count) of `job` have the ids gtile0 ..
 constexpr int kTnGroupChunk = 32;  // jobs per table-writer launch (kernel arguments stay under 4 KiB)
 struct TnJobChunk { TnJob j[kTnGroupChunk]; };
 __global__ void tn_group_table_kernel(TnJob* __restrict__ dst, TnJobChunk c, int first, int n) {
   const int i = threadIdx.x;
   if (i < n) dst[first + i] = c.j[i];
 }
+constexpr int kTnSegChunk = 192;
+struct TnSegChunk { TnSeg s[kTnSegChunk]; };
+__global__ void tn_group_seg_kernel(TnSeg* __restrict__ dst, TnSegChunk c, int first, int n) {
+  const int i = threadIdx.x;
+  if (i < n) dst[first + i] = c.s[i];
+}
+// stream-K region of the grouped kernel: [4 KiB: error word | 12 KiB: one flag per follower piece | slabs]
+constexpr int kTnMaxFollowers = 1024;
+constexpr size_t kTnSkHeadBytes = 16384;
+constexpr size_t kTnSkBytes = kTnSkHeadBytes + (size_t)kTnMaxFollowers * kSkSlabBytes;
 
-__global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob* __restrict__ jobs, int njobs, int T, int F, int S_rem,
-                                                                    int W, unsigned char* __restrict__ sk_ws, unsigned sk_seq) {
+__global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob* __restrict__ jobs, const TnSeg* __restrict__ segs, int nsegs,
+                                                                    int T, int F, int ns_split, unsigned char* __restrict__ sk_ws, unsigned sk_seq) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[163840];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const uint32_t OOB = 0xFFFFFFF0u;
   const int G = gridDim.x;
-  const int q = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);  // XCD-contiguous index
+  const int q = __builtin_amdgcn_readfirstlane((G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3));  // XCD-contiguous index
+  const int Rm = T - F * G;  // remainder tiles
 
   uint32_t voa[2], vob[2];
   i32x4 ra, rb;
   const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
   // ---- item = (job, tile, first stage, stages, kind) ----------------------------------------------------------------------
-  int jc = 0;                       // job cursor: tile ids only grow along a workgroup's walk
-  int round = 0;                    // whole-tile rounds done
-  int rp = -1, rp1 = 0;             // remainder phase: position / end of this workgroup's stage range (-1: not entered yet)
-  int rg = 0, rbase = 0;            // ... tile id and stage position of the first remainder tile of job jc that is not passed yet
+  int sc = 0;      // segment cursor
+  int round = 0;   // whole-tile rounds done
+  int rpiece = q;  // next remainder piece of this workgroup
   // the item being SET UP (next to compute): what the main loop needs stays in registers (lda, ldb, descriptors, lane offsets,
-  // stage count); what only the epilogue needs is re-read from the job table then -- (job, tile, kind | followers << 2) is all
-  // that is carried across the main loop, where the register file is full
+  // stage count); what only the epilogue needs is re-read from the job table then -- (job, tile, kind, piece) is all that is
+  // carried across the main loop, where the register file is full
   int lda = 0, ldb = 0, ns = 0, nx_j = 0, nx_t = 0, nx_info = 0;
-  auto job_tile_end = [&](int j) { return jobs[j].tile0 + jobs[j].ntiles; };
-  auto set_item = [&](int j, int t, int s0, int nst, int knd, int nfol) {  // tile t of job j, stages [s0, s0 + nst)
-    const TnJob jb = jobs[j];
+  // (values read from the tables are wave-uniform by construction; readfirstlane tells the compiler so -- they end up in scalar
+  //  operands of the DMA descriptors and stage offsets)
+  auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto find_seg = [&](int g) {  // segment that holds tile id g (ids mostly grow along a workgroup's walk: scan from the cursor)
+    if (g < rfl(segs[sc].gtile0)) sc = 0;
+    while (g >= rfl(segs[sc].gtile0) + rfl(segs[sc].count)) ++sc;
+  };
+  auto set_item = [&](int j, int t, int s0, int nst, int info) {  // tile t of job j, stages [s0, s0 + nst)
+    TnJob jb = jobs[j];
+    jb.lda = rfl(jb.lda); jb.ldb = rfl(jb.ldb); jb.ntn = rfl(jb.ntn); jb.M = rfl(jb.M); jb.N = rfl(jb.N); jb.R = rfl(jb.R);
     lda = jb.lda; ldb = jb.ldb;
-    const int tm = t / jb.ntn, tn = t - tm * jb.ntn;
+    const int tm = rfl(t / jb.ntn), tn = t - tm * jb.ntn;
     const int m0 = tm << 8, n0 = tn << 8;
-    ns = nst; nx_j = j; nx_t = t; nx_info = knd | (nfol << 2);
+    ns = nst; nx_j = j; nx_t = t; nx_info = info;
     const int rbeg = s0 * 32;
-    const int rows = (jb.R < rbeg + nst * 32 ? jb.R : rbeg + nst * 32) - rbeg;  // (>= 1: a piece never starts past the last row's stage)
+    const int rows = (jb.R < rbeg + nst * 32 ? jb.R : rbeg + nst * 32) - rbeg;  // (may be <= 0 for the last pieces of a short reduction: all zero-fill)
     const bf16* Ab = jb.A + (int64_t)rbeg * lda + m0;
     const bf16* Bb = jb.B + (int64_t)rbeg * ldb + n0;
     ra = make_srd(Ab, clamp_records(rows > 0 ? ((int64_t)(rows - 1) * lda + (jb.M - m0)) * 2 : 0));
@@ -1816,51 +1839,40 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob*
       vob[i] = (n0 + scol < jb.N) ? (uint32_t)((srow * ldb + scol) * 2) : OOB;
     }
   };
+  // info word of an item: bits 0-1 kind (0 whole tile, 1 follower piece, 2 owner piece), bits 2.. the piece id
   auto next_item = [&]() -> bool {
+    int it_job, it_tile, it_s0, it_ns, it_info;
     if (round < F) {  // whole tile of round `round`
       const int g = round * G + q;
       ++round;
-      while (g >= job_tile_end(jc)) ++jc;
-      set_item(jc, g - jobs[jc].tile0, 0, jobs[jc].nk, 0, 0);
-      return true;
+      find_seg(g);
+      const TnSeg sg = segs[sc];
+      it_job = rfl(sg.job);
+      it_tile = rfl(sg.tile_first) + (g - rfl(sg.gtile0));
+      it_s0 = 0;
+      it_ns = rfl(jobs[it_job].nk);
+      it_info = 0;
+    } else {
+      if (rpiece >= Rm * ns_split) return false;
+      const int p = rfl(rpiece);
+      rpiece = rfl(rpiece + G);
+      const int sp = rfl(p / Rm), tr = p - sp * Rm;  // split sp of remainder tile tr
+      find_seg(F * G + tr);
+      const TnSeg sg = segs[sc];
+      it_job = rfl(sg.job);
+      it_tile = rfl(sg.tile_first) + (F * G + tr - rfl(sg.gtile0));
+      const int units = rfl(jobs[it_job].nk) >> 2;   // units of 4 stages, dealt evenly over the splits (host: units >= ns_split)
+      const int u0 = rfl(sp * units / ns_split), u1 = rfl((sp + 1) * units / ns_split);  // (at most 16 splits, under 2^20 units: 32-bit)
+      it_s0 = u0 * 4;
+      it_ns = (u1 - u0) * 4;
+      it_info = (ns_split == 1 ? 0 : (sp + 1 == ns_split ? 2 : 1)) | (p << 2);
     }
-    if (S_rem == 0 || q >= W) return false;
-    if (rp < 0) {  // enter the remainder phase: this workgroup's range [rp, rp1) of the S_rem stages, cut at multiples of 4
-      rp = (int)(((int64_t)q * S_rem / W) & ~3ll);
-      rp1 = q + 1 == W ? S_rem : (int)(((int64_t)(q + 1) * S_rem / W) & ~3ll);
-      rg = F * G;
-      rbase = 0;
-      while (rg >= job_tile_end(jc)) ++jc;
-    }
-    if (rp >= rp1) return false;
-    // job that holds stage position rp: its tiles from rg on cover [rbase, rbase + n * nk)
-    while (true) {
-      const int n = job_tile_end(jc) - rg, nk = jobs[jc].nk;
-      if (rp < rbase + n * nk) break;
-      rbase += n * nk;
-      rg += n;
-      ++jc;
-    }
-    const int nk = jobs[jc].nk;
-    const int ti = (rp - rbase) / nk, off = (rp - rbase) - ti * nk;       // tile rg + ti, stage offset inside it
-    const int tile_end = rbase + (ti + 1) * nk;                           // stage position where that tile ends
-    const int len = (rp1 < tile_end ? rp1 : tile_end) - rp;
-    int knd = 0, nfol = 0;
-    if (off) knd = 1;  // continues a tile that another workgroup started
-    else if (len < nk) {  // starts a tile and leaves its end to the workgroups n with q < n < W and bound(n) < tile_end
-      knd = 2;
-      int64_t nmax = ((int64_t)tile_end * W - 1) / S_rem;
-      if (nmax > W - 1) nmax = W - 1;
-      nfol = (int)nmax - q;
-      if (nfol <= 0) { knd = 0; nfol = 0; }  // (cannot happen: len < nk means rp1 < tile_end, i.e. workgroup q + 1 starts inside the tile)
-    }
-    set_item(jc, rg + ti - jobs[jc].tile0, off, len, knd, nfol);
-    rp += len;
+    set_item(rfl(it_job), rfl(it_tile), rfl(it_s0), rfl(it_ns), rfl(it_info));
     return true;
   };
   auto stage = [&](int t) {
     const uint32_t base = lds0 + (t & 3) * 32768;
-    uint32_t ka = (uint32_t)(t * 32 * lda * 2), kb = (uint32_t)(t * 32 * ldb * 2);
+    uint32_t ka = (uint32_t)rfl(t * 32 * lda * 2), kb = (uint32_t)rfl(t * 32 * ldb * 2);
     asm volatile("" : "+s"(ka), "+s"(kb));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1913,13 +1925,13 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob*
     __builtin_amdgcn_s_barrier();
   };
 
-  if (!next_item()) return;
+  if (!rfl((int)next_item())) return;
   stage(0);
   stage(1);
   stage(2);
   while (true) {
     // the item being computed (next_item below overwrites the set-up variables)
-    const int cur_j = nx_j, cur_t = nx_t, cns = ns, ckind = nx_info & 3, cnf = nx_info >> 2;
+    const int cur_j = nx_j, cur_t = nx_t, cns = ns, ckind = nx_info & 3, cpiece = nx_info >> 2;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1973,7 +1985,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob*
     mma(1, a1, b_hi);
 
     __builtin_amdgcn_s_barrier();  // every wave has its last fragments: the ring is free
-    const bool more = next_item();
+    const bool more = rfl((int)next_item()) != 0;
     if (more) {
       stage(0);
       stage(1);
@@ -1982,7 +1994,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob*
     if (__builtin_expect(ckind == 1, 0)) {
       // FOLLOWER piece: raw accumulators in register order (1 KiB per store instruction), write-through, then ONE flag
       const __amdgpu_buffer_rsrc_t rs =
-          __builtin_amdgcn_make_buffer_rsrc(sk_ws + kSkHeadBytes + (size_t)q * kSkSlabBytes, 0, (uint32_t)kSkSlabBytes, 0x00020000);
+          __builtin_amdgcn_make_buffer_rsrc(sk_ws + kTnSkHeadBytes + (size_t)cpiece * kSkSlabBytes, 0, (uint32_t)kSkSlabBytes, 0x00020000);
       int ln = lane;
       asm volatile("" : "+v"(ln));
       const uint32_t off0 = (uint32_t)(wave * 32768 + ln * 16);
@@ -1994,17 +2006,16 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob*
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0)
-        __hip_atomic_store((unsigned*)sk_ws + q, (sk_pub(sk_seq) << 4) | xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (more) {  // the drain above also waited for the next item's first stages; nothing else to restore
-      }
+        __hip_atomic_store((unsigned*)(sk_ws + 4096) + cpiece, (sk_pub(sk_seq) << 4) | xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       if (__builtin_expect(ckind == 2, 0)) {
-        // OWNER: add the partials of the workgroups that continued this tile, order q+1, q+2, ... (protocol of the NT stream-K)
+        // OWNER (last split of its tile): add the partials of splits 0, 1, ... (protocol of the NT stream-K)
         int& s_bad = *reinterpret_cast<int*>(smem + 3 * 32768 + 65536 - 16);  // (last bytes of the patch area: not written before the epilogue)
-        for (int c2 = q + 1; c2 <= q + cnf; ++c2) {
+        const int tr = cpiece - (ns_split - 1) * Rm;
+        for (int c2 = tr; c2 < cpiece; c2 += Rm) {  // pieces of the same tile, splits 0 .. ns_split - 2
           if (threadIdx.x == 0) {
             unsigned spins = 0, f;
-            while (((f = __hip_atomic_load((unsigned*)sk_ws + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 4) != (sk_seq & 0x0FFFFFFFu) &&
+            while (((f = __hip_atomic_load((unsigned*)(sk_ws + 4096) + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 4) != (sk_seq & 0x0FFFFFFFu) &&
                    spins < (1u << 22)) {
               __builtin_amdgcn_s_sleep(8);
               ++spins;
@@ -2016,7 +2027,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob*
           __syncthreads();
           const bool bad = s_bad != 0;
           const __amdgpu_buffer_rsrc_t rs =
-              __builtin_amdgcn_make_buffer_rsrc(sk_ws + kSkHeadBytes + (size_t)c2 * kSkSlabBytes, 0, (uint32_t)kSkSlabBytes, 0x00020000);
+              __builtin_amdgcn_make_buffer_rsrc(sk_ws + kTnSkHeadBytes + (size_t)c2 * kSkSlabBytes, 0, (uint32_t)kSkSlabBytes, 0x00020000);
           int ln = lane;
           asm volatile("" : "+v"(ln));
           const uint32_t off0 = (uint32_t)(wave * 32768 + ln * 16);
@@ -2040,7 +2051,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob*
         }
       }
       unsigned char* patch = smem + 3 * 32768 + wave * 8192;
-      const TnJob cj = jobs[cur_j];
+      TnJob cj = jobs[cur_j];
+      cj.ntn = rfl(cj.ntn); cj.M = rfl(cj.M); cj.N = rfl(cj.N); cj.ldc = rfl(cj.ldc);
       const int ctm = cur_t / cj.ntn, cm0 = ctm << 8, cn0 = (cur_t - ctm * cj.ntn) << 8, cM = cj.M, cN = cj.N;
       Epilogue eo;
       eo.bias = nullptr; eo.residual = nullptr; eo.ldr = 0; eo.act = HCT_ACT_NONE; eo.aux = nullptr; eo.aux_dtype = HCT_F32; eo.ldaux = 0;
@@ -2364,6 +2376,8 @@ size_t hct_gemm_nt_flags_offset(size_t workspace_bytes) {
 
 // ---- grouped wgrad (gemm_bf16_tn_group_kernel) --------------------------------------------------------------------------
 static size_t tn_group_table_bytes(int n) { return align_up((size_t)n * sizeof(TnJob), 4096); }
+static int tn_group_seg_capacity(int n) { return 16 * n + 64; }
+static size_t tn_group_seg_bytes(int n) { return align_up((size_t)tn_group_seg_capacity(n) * sizeof(TnSeg), 4096); }
 
 }  // extern "C"
 namespace hct {
@@ -2399,7 +2413,91 @@ static TnJob tn_group_job(const hct_gemm_args* a, int tile0) {
   return j;
 }
 
-size_t hct_gemm_tn_group_workspace_bytes(int n_jobs) { return n_jobs > 0 ? tn_group_table_bytes(n_jobs) + kSkBytes : 0; }
+// Tile order of a grouped launch.  Jobs by falling reduction length (stable), so that the whole-tile rounds are homogeneous and the
+// shortest products end up in the remainder; inside a class of equal length the tiles are dealt in windows of 32 ids (= what the
+// 32 workgroups of an XCD work on at a time): whole chunks of 32 tiles of ONE product while there are any, the left-overs packed
+// largest-first into the windows that remain (a left-over is cut only where nothing fits).
+static std::vector<TnSeg> tn_group_segments(const std::vector<TnJob>& jobs) {
+  std::vector<int> order(jobs.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return jobs[x].nk > jobs[y].nk; });
+  std::vector<TnSeg> segs;
+  int gid = 0;
+  auto emit = [&](int job, int first, int count) {
+    if (!segs.empty() && segs.back().job == job && segs.back().tile_first + segs.back().count == first) segs.back().count += count;
+    else segs.push_back(TnSeg{job, first, count, gid});
+    gid += count;
+  };
+  size_t i = 0;
+  while (i < order.size()) {
+    size_t e = i;
+    while (e < order.size() && jobs[order[e]].nk == jobs[order[i]].nk) ++e;
+    struct Item { int job, first, count; };
+    std::vector<Item> full, rest;  // chunks of 32, left-overs (< 32)
+    for (size_t k = i; k < e; ++k) {
+      const int j = order[k], nt = jobs[j].ntiles;
+      for (int c = 0; c + 32 <= nt; c += 32) full.push_back(Item{j, c, 32});
+      if (nt % 32) rest.push_back(Item{j, nt / 32 * 32, nt % 32});
+    }
+    std::stable_sort(rest.begin(), rest.end(), [](const Item& x, const Item& y) { return x.count > y.count; });
+    size_t fi = 0;
+    while (fi < full.size() || !rest.empty()) {
+      const int room = 32 - gid % 32;
+      if (room == 32 && fi < full.size()) { emit(full[fi].job, full[fi].first, 32); ++fi; continue; }
+      // the largest left-over that fits the window; none: a piece of the largest one (or of a whole chunk) closes the window
+      size_t pick = rest.size();
+      for (size_t k = 0; k < rest.size(); ++k)
+        if (rest[k].count <= room) { pick = k; break; }
+      if (pick < rest.size()) {
+        emit(rest[pick].job, rest[pick].first, rest[pick].count);
+        rest.erase(rest.begin() + pick);
+      } else if (!rest.empty()) {
+        emit(rest[0].job, rest[0].first, room);
+        rest[0].first += room; rest[0].count -= room;
+        std::stable_sort(rest.begin(), rest.end(), [](const Item& x, const Item& y) { return x.count > y.count; });
+      } else {  // only whole chunks left and the window is open: cut one
+        Item it = full[fi++];
+        emit(it.job, it.first, room);
+        rest.push_back(Item{it.job, it.first + room, 32 - room});
+      }
+    }
+    i = e;
+  }
+  return segs;
+}
+
+// splits of the remainder tiles: least (rounds of pieces) / splits, a small price per split for the fix-up; every piece at least
+// 4 stages, at most kTnMaxFollowers follower pieces
+static int tn_group_splits(int Rm, int G, int min_nk) {
+  if (Rm <= 0) return 1;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int sp = 1; sp <= 16; ++sp) {
+    if (sp > 1 && ((int64_t)(sp - 1) * Rm > kTnMaxFollowers || min_nk / 4 < sp * 4)) break;  // (pieces of at least 16 stages)
+    const double cost = (double)(((int64_t)Rm * sp + G - 1) / G) / sp + 0.004 * sp;
+    if (cost < best_cost - 1e-12) { best_cost = cost; best = sp; }
+  }
+  return best;
+}
+
+size_t hct_gemm_tn_group_workspace_bytes(int n_jobs) { return n_jobs > 0 ? tn_group_table_bytes(n_jobs) + tn_group_seg_bytes(n_jobs) + kTnSkBytes : 0; }
+
+static int tn_group_build(const hct_gemm_args* jobs, int n, bool check, std::vector<TnJob>& tj, std::vector<TnSeg>& segs) {
+  tj.resize(n);
+  int tile0 = 0;
+  for (int i = 0; i < n; ++i) {
+    if (check)
+      if (int rc = tn_group_check(jobs + i, i)) return rc;
+    tj[i] = tn_group_job(jobs + i, tile0);
+    tile0 += tj[i].ntiles;
+  }
+  segs = tn_group_segments(tj);
+  if ((int)segs.size() > tn_group_seg_capacity(n)) {
+    set_error("hct_gemm_tn_group: %zu tile segments exceed the workspace's table (%d)", segs.size(), tn_group_seg_capacity(n));
+    return HCT_E_WORKSPACE;
+  }
+  return 0;
+}
 
 int hct_gemm_tn_group_prepare(const hct_gemm_args* jobs, int n, void* workspace, size_t workspace_bytes, void* stream) {
   HCT_REQUIRE(jobs && n > 0 && n <= 4096 && workspace, "hct_gemm_tn_group_prepare: bad arguments");
@@ -2408,19 +2506,27 @@ int hct_gemm_tn_group_prepare(const hct_gemm_args* jobs, int n, void* workspace,
     return HCT_E_WORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  int tile0 = 0;
+  std::vector<TnJob> tj;
+  std::vector<TnSeg> segs;
+  if (int rc = tn_group_build(jobs, n, true, tj, segs)) return rc;
   for (int first = 0; first < n; first += kTnGroupChunk) {
     TnJobChunk c;
     memset(&c, 0, sizeof(c));
     const int cnt = std::min(kTnGroupChunk, n - first);
-    for (int i = 0; i < cnt; ++i) {
-      if (int rc = tn_group_check(jobs + first + i, first + i)) return rc;
-      c.j[i] = tn_group_job(jobs + first + i, tile0);
-      tile0 += c.j[i].ntiles;
-    }
+    for (int i = 0; i < cnt; ++i) c.j[i] = tj[first + i];
     hipLaunchKernelGGL(tn_group_table_kernel, dim3(1), dim3(64), 0, s, (TnJob*)workspace, c, first, cnt);
   }
-  if (int rc = check_hip(hipMemsetAsync((unsigned char*)workspace + tn_group_table_bytes(n), 0, kSkHeadBytes, s), "hct_gemm_tn_group: flag reset")) return rc;
+  TnSeg* dsegs = (TnSeg*)((unsigned char*)workspace + tn_group_table_bytes(n));
+  for (int first = 0; first < (int)segs.size(); first += kTnSegChunk) {
+    TnSegChunk c;
+    memset(&c, 0, sizeof(c));
+    const int cnt = std::min(kTnSegChunk, (int)segs.size() - first);
+    for (int i = 0; i < cnt; ++i) c.s[i] = segs[first + i];
+    hipLaunchKernelGGL(tn_group_seg_kernel, dim3(1), dim3(256), 0, s, dsegs, c, first, cnt);
+  }
+  if (int rc = check_hip(hipMemsetAsync((unsigned char*)workspace + tn_group_table_bytes(n) + tn_group_seg_bytes(n), 0, kTnSkHeadBytes, s),
+                         "hct_gemm_tn_group: flag reset"))
+    return rc;
   HCT_CHECK_LAUNCH("hct_gemm_tn_group_prepare");
   return 0;
 }
@@ -2429,36 +2535,30 @@ int hct_gemm_tn_group_run(const hct_gemm_args* jobs, int n, void* workspace, siz
   HCT_REQUIRE(jobs && n > 0 && workspace && workspace_bytes >= hct_gemm_tn_group_workspace_bytes(n), "hct_gemm_tn_group_run: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const int G = std::min(num_cus(), kSkMaxWgs);
+  std::vector<TnJob> tj;
+  std::vector<TnSeg> segs;
+  if (int rc = tn_group_build(jobs, n, false, tj, segs)) return rc;  // (the same order `prepare` wrote: host arithmetic only)
   int T = 0;
   double flops = 0, bytes = 0;
-  std::vector<int> nk(n), nt(n);
   for (int i = 0; i < n; ++i) {
-    const TnJob j = tn_group_job(jobs + i, T);
-    nk[i] = j.nk; nt[i] = j.ntiles;
-    T += j.ntiles;
+    T += tj[i].ntiles;
     flops += 2.0 * jobs[i].M * jobs[i].N * jobs[i].K;
     bytes += 2.0 * jobs[i].K * (jobs[i].M + jobs[i].N) + 4.0 * jobs[i].M * jobs[i].N;
   }
-  const int F = T / G;
-  int64_t S_rem = 0;
-  {
-    int t = 0;
-    for (int i = 0; i < n; ++i) {  // stages of the tiles with id >= F * G
-      const int lo = std::max(t, F * G), hi = t + nt[i];
-      if (hi > lo) S_rem += (int64_t)(hi - lo) * nk[i];
-      t = hi;
-    }
-  }
-  HCT_REQUIRE(S_rem < (1ll << 30), "hct_gemm_tn_group_run: remainder too long");
-  const int W = S_rem > 0 ? (int)std::min<int64_t>(G, std::max<int64_t>(1, S_rem / 16)) : 0;
+  const int F = T / G, Rm = T - F * G;
+  int min_nk = 1 << 30;  // shortest reduction among the remainder tiles (ids >= F * G)
+  for (const TnSeg& sg : segs)
+    if (sg.gtile0 + sg.count > F * G) min_nk = std::min(min_nk, tj[sg.job].nk);
+  const int ns_split = tn_group_splits(Rm, G, min_nk);
   ProfScope ps(PROF_GEMM_TN, flops, s, bytes);
-  ps.tag(n, T, (int)S_rem, -1, T, T - F * G);
+  ps.tag(n, T, ns_split, -1, T, Rm);
   static unsigned seq = 0;
   unsigned sk_seq = (++seq) & 0x0FFFFFFFu;
   if (sk_seq == 0) sk_seq = (++seq) & 0x0FFFFFFFu;
   if (g_sk_drop) sk_seq |= 0x80000000u;
-  hipLaunchKernelGGL(gemm_bf16_tn_group_kernel, dim3(G), dim3(512), 0, s, (const TnJob*)workspace, n, T, F, (int)S_rem, W,
-                     (unsigned char*)workspace + tn_group_table_bytes(n), sk_seq);
+  unsigned char* base = (unsigned char*)workspace;
+  hipLaunchKernelGGL(gemm_bf16_tn_group_kernel, dim3(G), dim3(512), 0, s, (const TnJob*)base, (const TnSeg*)(base + tn_group_table_bytes(n)),
+                     (int)segs.size(), T, F, ns_split, base + tn_group_table_bytes(n) + tn_group_seg_bytes(n), sk_seq);
   HCT_CHECK_LAUNCH("hct_gemm_tn_group_run");
   return 0;
 }

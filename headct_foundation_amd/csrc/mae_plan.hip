@@ -33,7 +33,7 @@ struct Act { size_t off; int64_t rows, cols; int dtype; };
 // pre-activation [M,m], wrt h_mid [M,d], wrt qkv [M,3d].  They stay untouched until the block's weight gradients have run (the
 // grouped launch, see flush_wgrads): a ring of sets per side.
 struct BlockG { size_t out, big, mid, qkv; };
-constexpr int kWgSlots = 12;  // grouped weight-gradient launches per backward, at most (each keeps a prepared job table)
+constexpr int kWgSlots = 8;   // grouped weight-gradient launches per backward, at most (each keeps a prepared job table)
 
 }  // namespace
 

@@ -246,7 +246,7 @@ def _tn_group(lib, ops, reps=1):
     for _ in range(reps):
         _lib.check(lib.hct_gemm_tn_group_run(C.cast(jobs, C.c_void_p), n, ws.data_ptr(), nbytes, _st()), "tn_group_run")
     torch.cuda.synchronize()
-    flags = ws[lib.hct_gemm_tn_group_workspace_bytes(n) - (256 * 262144 + 4096):][:4096].view(torch.int32)
+    flags = ws[lib.hct_gemm_tn_group_workspace_bytes(n) - (1024 * 262144 + 16384):][:4096].view(torch.int32)  # head of the stream-K region
     if int(flags[512]) != 0:  # a partial never arrived: the owners' tiles must then be NaN, not silently wrong
         assert any(torch.isnan(o).any() for o in outs)
     assert int(flags[512]) == 0, "a stream-K partial of the grouped wgrad never arrived"
@@ -259,7 +259,7 @@ def test_gemm_tn_group(lib, cuda, case):
     every product against a float reference (bf16 products are exact in fp32: 2e-5), repeat launches bit-identical, and the same
     bits on a 240-workgroup grid split differently (reserve16: different partial sums, so 1e-5 rather than bit equality)."""
     shapes = {
-        # (R, M, N) per job: 108 tiles on 256 CUs -> no whole round, every tile shared by 2-3 workgroups
+        # (R, M, N) per job: 108 tiles on 256 CUs -> no whole round, every tile split over the reduction
         "stream_k_only": [(2000, 768, 3072), (2000, 3072, 768), (2016, 768, 768), (2000, 2304, 768)],
         # 8 x 72 = 576 tiles -> two whole rounds + 64 remainder tiles; two reduction lengths
         "rounds_plus_remainder": [(300, 1536, 3072)] * 5 + [(1000, 3072, 1536)] * 3,
