@@ -112,6 +112,10 @@ _PROTOS = {
     "hct_l2norm_rows_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "hct_weight_norm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "hct_weight_norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "hct_bn_gelu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "hct_bn_gelu_bwd_sums": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "hct_bn_gelu_bwd_apply": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, C.c_double, c_int, c_int, c_void_p, c_int,
+                                      c_void_p]),
     "hct_hu_window": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "hct_augment_volume": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "hct_gaussian_smooth3d": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

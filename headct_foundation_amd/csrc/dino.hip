@@ -210,6 +210,69 @@ __global__ void __launch_bounds__(256) weight_norm_bwd_kernel(const float* __res
   if (dg && lane == 0) dg[row] = dot;
 }
 
+// ---- BatchNorm1d (affine) + GELU of the projection head with use_bn (dino_head.py:15-21: Linear -> BatchNorm1d -> GELU) ---------
+// u [M, D] fp32 = the Linear's output; mean / var per feature: the batch statistics in training (hct_batchnorm_stats; all-reduced by
+// the caller under data parallelism, as SyncBatchNorm does, main_pretrain_dino.py:183-185) or the running ones in eval.
+//   xhat = (u - mean) * rsqrt(var + eps);  y = gamma * xhat + beta;  h = gelu(y) (exact erf);  dact = gelu'(y)
+template <typename T>
+__global__ void __launch_bounds__(256) bn_gelu_fwd_kernel(const float* __restrict__ u, const float* __restrict__ mean, const float* __restrict__ var,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int64_t n4, int D,
+                                                          T* __restrict__ h, float* __restrict__ xhat, float* __restrict__ dact) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int k = (int)((i * 4) % D);
+  const f32x4 uv = Vec4<float>::load(u + i * 4), mu = Vec4<float>::load(mean + k), vr = Vec4<float>::load(var + k);
+  const f32x4 g = Vec4<float>::load(gamma + k), b = Vec4<float>::load(beta + k);
+  f32x4 xh, hv, dv;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    xh[e] = (uv[e] - mu[e]) * (1.0f / sqrtf(vr[e] + eps));
+    const float y = g[e] * xh[e] + b[e];
+    hv[e] = gelu_erf(y);
+    dv[e] = dgelu_erf(y);
+  }
+  Vec4<T>::store(h + i * 4, hv);
+  if (xhat) Vec4<float>::store(xhat + i * 4, xh);
+  if (dact) Vec4<float>::store(dact + i * 4, dv);
+}
+
+// sums[0][k] = sum_rows dy, sums[1][k] = sum_rows dy * xhat, dy = dh * dact  (= dbeta, dgamma of this rank's rows); rows in order
+template <typename T>
+__global__ void __launch_bounds__(256) bn_gelu_bwd_sums_kernel(const T* __restrict__ dh, const float* __restrict__ dact, const float* __restrict__ xhat,
+                                                               int M, int D, float* __restrict__ sums) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= D) return;
+  float sb = 0.f, sg = 0.f;
+  for (int r = 0; r < M; ++r) {
+    const size_t o = (size_t)r * D + k;
+    const float dy = to_f32(dh[o]) * dact[o];
+    sb += dy;
+    sg += dy * xhat[o];
+  }
+  sums[k] = sb;
+  sums[D + k] = sg;
+}
+
+// du = gamma * rstd * (dy - sums[0] / count - xhat * sums[1] / count): gradient wrt the Linear's output (count = rows of ALL ranks
+// that shared the statistics; sums all-reduced by the caller then)
+template <typename T, typename TO>
+__global__ void __launch_bounds__(256) bn_gelu_bwd_apply_kernel(const T* __restrict__ dh, const float* __restrict__ dact, const float* __restrict__ xhat,
+                                                                const float* __restrict__ gamma, const float* __restrict__ var, float eps,
+                                                                const float* __restrict__ sums, float inv_count, int64_t n4, int D, TO* __restrict__ du) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int k = (int)((i * 4) % D);
+  const f32x4 dhv = Vec4<T>::load(dh + i * 4), da = Vec4<float>::load(dact + i * 4), xh = Vec4<float>::load(xhat + i * 4);
+  const f32x4 g = Vec4<float>::load(gamma + k), vr = Vec4<float>::load(var + k), sb = Vec4<float>::load(sums + k), sg = Vec4<float>::load(sums + D + k);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float dy = dhv[e] * da[e];
+    o[e] = g[e] * (1.0f / sqrtf(vr[e] + eps)) * (dy - sb[e] * inv_count - xh[e] * sg[e] * inv_count);
+  }
+  Vec4<TO>::store(du + i * 4, o);
+}
+
 }  // namespace
 }  // namespace hct
 
@@ -295,4 +358,40 @@ int hct_ema_update(float* momentum_params, const float* params, int64_t n, doubl
   return 0;
 }
 
+int hct_bn_gelu_fwd(const float* u, const float* mean, const float* var, const float* gamma, const float* beta, float eps, int M, int D, void* h,
+                    int h_dtype, float* xhat, float* dact, void* stream) {
+  HCT_REQUIRE(u && mean && var && gamma && beta && h && M > 0 && D > 0 && D % 4 == 0, "hct_bn_gelu_fwd: bad arguments (D must be a multiple of 4)");
+  const int64_t n4 = (int64_t)M * D / 4;
+  HCT_DISPATCH_DTYPE(h_dtype, T, hipLaunchKernelGGL(bn_gelu_fwd_kernel<T>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, mean, var,
+                                                     gamma, beta, eps, n4, D, (T*)h, xhat, dact));
+  HCT_CHECK_LAUNCH("hct_bn_gelu_fwd");
+  return 0;
+}
+
+int hct_bn_gelu_bwd_sums(const void* dh, int dh_dtype, const float* dact, const float* xhat, int M, int D, float* sums, void* stream) {
+  HCT_REQUIRE(dh && dact && xhat && sums && M > 0 && D > 0, "hct_bn_gelu_bwd_sums: bad arguments");
+  HCT_DISPATCH_DTYPE(dh_dtype, T, hipLaunchKernelGGL(bn_gelu_bwd_sums_kernel<T>, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const T*)dh, dact,
+                                                      xhat, M, D, sums));
+  HCT_CHECK_LAUNCH("hct_bn_gelu_bwd_sums");
+  return 0;
+}
+
+int hct_bn_gelu_bwd_apply(const void* dh, int dh_dtype, const float* dact, const float* xhat, const float* gamma, const float* var, float eps,
+                          const float* sums, double count, int M, int D, void* du, int du_dtype, void* stream) {
+  HCT_REQUIRE(dh && dact && xhat && gamma && var && sums && du && M > 0 && D > 0 && D % 4 == 0 && count >= 1.0, "hct_bn_gelu_bwd_apply: bad arguments");
+  HCT_REQUIRE(dh_dtype == du_dtype || du_dtype == HCT_F32, "hct_bn_gelu_bwd_apply: du is written in the dtype of dh, or fp32");
+  const int64_t n4 = (int64_t)M * D / 4;
+  const float inv = (float)(1.0 / count);
+  const dim3 grid((unsigned)((n4 + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+  if (du_dtype == HCT_F32 && dh_dtype == HCT_BF16)
+    hipLaunchKernelGGL((bn_gelu_bwd_apply_kernel<bf16, float>), grid, dim3(256), 0, s, (const bf16*)dh, dact, xhat, gamma, var, eps, sums, inv, n4, D, (float*)du);
+  else
+    HCT_DISPATCH_DTYPE(dh_dtype, T, hipLaunchKernelGGL((bn_gelu_bwd_apply_kernel<T, T>), grid, dim3(256), 0, s, (const T*)dh, dact, xhat, gamma, var, eps, sums,
+                                                        inv, n4, D, (T*)du));
+  HCT_CHECK_LAUNCH("hct_bn_gelu_bwd_apply");
+  return 0;
+}
+
 }  // extern "C"
+

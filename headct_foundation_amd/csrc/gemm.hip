@@ -1073,6 +1073,9 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     }
     return false;
   };
+#ifdef HCT_PRIO_YOUNG
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   if (SK && it_first) take_item(it_first);
   else if (!next_item()) return;  // (only with stream-K: more workgroups than K ranges and no whole tiles)
   stage_pair(0);
@@ -1925,6 +1928,9 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob*
     __builtin_amdgcn_s_barrier();
   };
 
+#ifdef HCT_PRIO_YOUNG  /* experiment: static priority for the second-dispatched half of the waves (MI355X_MICROARCH.md, two waves per SIMD, item 4) */
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   if (!rfl((int)next_item())) return;
   stage(0);
   stage(1);

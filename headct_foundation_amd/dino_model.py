@@ -230,11 +230,31 @@ class _HeadFunction(torch.autograd.Function):
         x = x.to(cd).contiguous()
         W = head._working_weights(cd)
         mk = lambda n, dt=cd: torch.empty(M, n, dtype=dt, device=dev)
-        u1, h1, u2, h2 = mk(H), mk(H), mk(H), mk(H)
-        _gemm(lib, x, W["mlp.0.weight"], 0, 1, M, H, D, h1, bias=head.mlp[0].bias, act=1, aux=u1)      # Linear + GELU (exact erf)
-        _gemm(lib, h1, W["mlp.2.weight"], 0, 1, M, H, H, h2, bias=head.mlp[2].bias, act=1, aux=u2)
+        l0, l1, l2 = head._lin
+        bn_saved = []
+        if not head.use_bn:
+            u1, h1, u2, h2 = mk(H), mk(H), mk(H), mk(H)
+            _gemm(lib, x, W[f"mlp.{l0}.weight"], 0, 1, M, H, D, h1, bias=head.mlp[l0].bias, act=1, aux=u1)      # Linear + GELU (exact erf)
+            _gemm(lib, h1, W[f"mlp.{l1}.weight"], 0, 1, M, H, H, h2, bias=head.mlp[l1].bias, act=1, aux=u2)
+        else:
+            # Linear -> BatchNorm1d -> GELU (dino_head.py:15-21): the Linear's output stays fp32, the statistics are the batch's in
+            # training (shared over the ranks like the reference's SyncBatchNorm, main_pretrain_dino.py:183-185) and the running
+            # ones in eval; xhat and gelu'(y) are kept for the backward
+            u1 = u2 = None
+            h1, h2 = mk(H), mk(H)
+            inp, width = x, D
+            for li, bi, hout in ((l0, head._bn[0], h1), (l1, head._bn[1], h2)):
+                u = mk(H, torch.float32)
+                _gemm(lib, inp, W[f"mlp.{li}.weight"], 0, 1, M, H, width, u, bias=head.mlp[li].bias)
+                bn = head.mlp[bi]
+                mean, var, count = head._bn_statistics(lib, bn, u, M, H)
+                xhat, dact = mk(H, torch.float32), mk(H, torch.float32)
+                _lib.check(lib.hct_bn_gelu_fwd(u.data_ptr(), mean.data_ptr(), var.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), M, H,
+                                               hout.data_ptr(), _code(hout), xhat.data_ptr(), dact.data_ptr(), _st()), "hct_bn_gelu_fwd")
+                bn_saved.append((xhat, dact, var, count))
+                inp, width = hout, H
         z = mk(Bn, torch.float32)
-        _gemm(lib, h2, W["mlp.4.weight"], 0, 1, M, Bn, H, z, bias=head.mlp[4].bias)
+        _gemm(lib, h2, W[f"mlp.{l2}.weight"], 0, 1, M, Bn, H, z, bias=head.mlp[l2].bias)
         zn, inv_z = mk(Bn), torch.empty(M, dtype=torch.float32, device=dev)
         _lib.check(lib.hct_l2norm_rows_fwd(z.data_ptr(), M, Bn, zn.data_ptr(), _code(zn), inv_z.data_ptr(), _st()), "hct_l2norm_rows_fwd")
         wn = torch.empty(K, Bn, dtype=cd, device=dev)
@@ -250,7 +270,7 @@ class _HeadFunction(torch.autograd.Function):
         if not (cd == torch.bfloat16 and M % 16 == 0 and Bn % 16 == 0):
             wn_t = torch.empty(Bn, K, dtype=cd, device=dev)
             _lib.check(lib.hct_transpose_cast(wn.data_ptr(), _code(wn), wn_t.data_ptr(), _code(wn_t), K, Bn, _st()), "hct_transpose_cast")
-        ctx.head, ctx.saved, ctx.wn = head, (x, u1, h1, u2, h2, zn, inv_z, wn_t, inv_v, W), wn
+        ctx.head, ctx.saved, ctx.wn, ctx.bn_saved = head, (x, u1, h1, u2, h2, zn, inv_z, wn_t, inv_v, W), wn, bn_saved
         return logits
 
     @staticmethod
@@ -286,45 +306,79 @@ class _HeadFunction(torch.autograd.Function):
         dzc = dz.to(cd)
         ws = torch.empty(max(16, lib.hct_colsum_workspace_bytes(M, max(H, Bn))), dtype=torch.uint8, device=dev)
         colsum = lambda t, n, name: _lib.check(lib.hct_colsum(t.data_ptr(), _code(t), M, n, n, gv(name).data_ptr(), ws.data_ptr(), ws.numel(), _st()), "hct_colsum")
-        # mlp.4
-        _gemm(lib, dzc, h2, 1, 0, Bn, H, M, gv("mlp.4.weight"))
-        colsum(dzc, Bn, "mlp.4.bias")
+        l0, l1, l2 = head._lin
+        # last Linear of the MLP
+        _gemm(lib, dzc, h2, 1, 0, Bn, H, M, gv(f"mlp.{l2}.weight"))
+        colsum(dzc, Bn, f"mlp.{l2}.bias")
         du2 = torch.empty(M, H, dtype=cd, device=dev)
-        _gemm(lib, dzc, W["mlp.4.weight_t"], 0, 1, M, H, Bn, du2, act=2, aux=u2)        # (dz . W4) * gelu'(u2)
-        # mlp.2
-        _gemm(lib, du2, h1, 1, 0, H, H, M, gv("mlp.2.weight"))
-        colsum(du2, H, "mlp.2.bias")
         du1 = torch.empty(M, H, dtype=cd, device=dev)
-        _gemm(lib, du2, W["mlp.2.weight_t"], 0, 1, M, H, H, du1, act=2, aux=u1)
-        # mlp.0
-        _gemm(lib, du1, x, 1, 0, H, D, M, gv("mlp.0.weight"))
-        colsum(du1, H, "mlp.0.bias")
+        if not head.use_bn:
+            _gemm(lib, dzc, W[f"mlp.{l2}.weight_t"], 0, 1, M, H, Bn, du2, act=2, aux=u2)        # (dz . W) * gelu'(u2)
+        else:
+            dh2 = torch.empty(M, H, dtype=cd, device=dev)
+            _gemm(lib, dzc, W[f"mlp.{l2}.weight_t"], 0, 1, M, H, Bn, dh2)
+            head._bn_backward(lib, head.mlp[head._bn[1]], dh2, ctx.bn_saved[1], M, H, du2, gv)
+        # second Linear
+        _gemm(lib, du2, h1, 1, 0, H, H, M, gv(f"mlp.{l1}.weight"))
+        colsum(du2, H, f"mlp.{l1}.bias")
+        if not head.use_bn:
+            _gemm(lib, du2, W[f"mlp.{l1}.weight_t"], 0, 1, M, H, H, du1, act=2, aux=u1)
+        else:
+            dh1 = torch.empty(M, H, dtype=cd, device=dev)
+            _gemm(lib, du2, W[f"mlp.{l1}.weight_t"], 0, 1, M, H, H, dh1)
+            head._bn_backward(lib, head.mlp[head._bn[0]], dh1, ctx.bn_saved[0], M, H, du1, gv)
+        # first Linear
+        _gemm(lib, du1, x, 1, 0, H, D, M, gv(f"mlp.{l0}.weight"))
+        colsum(du1, H, f"mlp.{l0}.bias")
         dx = torch.empty(M, D, dtype=torch.float32, device=dev)
-        _gemm(lib, du1, W["mlp.0.weight_t"], 0, 1, M, D, H, dx)
+        _gemm(lib, du1, W[f"mlp.{l0}.weight_t"], 0, 1, M, D, H, dx)
         head._attach_grads()
         return None, None, dx
 
 
+class _BatchNorm(_Holder):
+    """Parameters and buffers of nn.BatchNorm1d(n) / SyncBatchNorm under the reference's names (weight, bias, running_mean, running_var,
+    num_batches_tracked): a holder, the arithmetic runs in the head's kernels."""
+
+    def __init__(self, n: int, eps: float = 1e-5, momentum: float = 0.1):
+        super().__init__()
+        self.eps, self.momentum = eps, momentum
+        self.weight = nn.Parameter(torch.ones(n))
+        self.bias = nn.Parameter(torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
 class DINOHead(nn.Module, _FlatParams):
-    """Reference DINOHead (src/models/dino_head.py) with use_bn=False and nlayers=3."""
+    """Reference DINOHead (src/models/dino_head.py) with nlayers=3; use_bn=False (the reference yaml) or True (the default of
+    config.py:86: Linear -> BatchNorm1d -> GELU, batch statistics shared over the ranks like the SyncBatchNorm the reference converts
+    to, main_pretrain_dino.py:183-185)."""
 
     def __init__(self, in_dim, out_dim, use_bn=False, norm_last_layer=True, nlayers=3, hidden_dim=2048, bottleneck_dim=256,
                  compute_dtype: str = "bf16"):
         super().__init__()
-        if use_bn or nlayers != 3:
-            raise NotImplementedError("HIP DINOHead: use_bn=False, nlayers=3 (the reference yaml's head)")
+        if nlayers != 3:
+            raise NotImplementedError("HIP DINOHead: nlayers=3 (the reference's head)")
         if in_dim % 4 or hidden_dim % 4 or bottleneck_dim % 4 or out_dim % 4:
             raise HctError("HIP DINOHead: dimensions must be multiples of 4")
         self.in_dim, self.out_dim, self.hidden_dim, self.bottleneck_dim = in_dim, out_dim, hidden_dim, bottleneck_dim
         self.compute_dtype = compute_dtype
-        mlp = [_Affine(hidden_dim, in_dim, bias_shape=(hidden_dim,)), _Holder(), _Affine(hidden_dim, hidden_dim, bias_shape=(hidden_dim,)),
-               _Holder(), _Affine(bottleneck_dim, hidden_dim, bias_shape=(bottleneck_dim,))]
-        self.mlp = nn.Sequential(*mlp)  # indices 0 / 2 / 4 carry the Linear parameters, as in the reference's Sequential
+        self.use_bn = bool(use_bn)
+        lin = lambda o, i: _Affine(o, i, bias_shape=(o,))
+        if self.use_bn:  # Sequential indices as in the reference: Linear 0, BatchNorm1d 1, GELU 2, Linear 3, BatchNorm1d 4, GELU 5, Linear 6
+            mlp = [lin(hidden_dim, in_dim), _BatchNorm(hidden_dim), _Holder(), lin(hidden_dim, hidden_dim), _BatchNorm(hidden_dim), _Holder(),
+                   lin(bottleneck_dim, hidden_dim)]
+            self._lin, self._bn = (0, 3, 6), (1, 4)
+        else:
+            mlp = [lin(hidden_dim, in_dim), _Holder(), lin(hidden_dim, hidden_dim), _Holder(), lin(bottleneck_dim, hidden_dim)]
+            self._lin, self._bn = (0, 2, 4), ()
+        self.mlp = nn.Sequential(*mlp)  # the Linear / BatchNorm indices carry the parameters, as in the reference's Sequential
         self.last_layer = _Holder()
         self.last_layer.weight_g = nn.Parameter(torch.ones(out_dim, 1), requires_grad=not norm_last_layer)
         self.last_layer.weight_v = nn.Parameter(torch.empty(out_dim, bottleneck_dim))
         with torch.no_grad():
-            for i in (0, 2, 4):
+            for i in self._lin:
                 nn.init.trunc_normal_(self.mlp[i].weight, std=.02)
                 nn.init.constant_(self.mlp[i].bias, 0)
             nn.init.kaiming_uniform_(self.last_layer.weight_v, a=math.sqrt(5))  # nn.Linear default, then weight_norm splits g / v
@@ -357,7 +411,7 @@ class DINOHead(nn.Module, _FlatParams):
         lib = _lib.load()
         code = HCT_BF16 if cd == torch.bfloat16 else HCT_F32
         out = {"dtype": cd}
-        for i in (0, 2, 4):
+        for i in self._lin:
             w = self.mlp[i].weight.detach()
             if cd == torch.float32:
                 out[f"mlp.{i}.weight"] = w
@@ -370,6 +424,48 @@ class DINOHead(nn.Module, _FlatParams):
             out[f"mlp.{i}.weight_t"] = t
         self._wcache, self._wver = out, self._weights_version
         return out
+
+    def _bn_statistics(self, lib, bn, u: torch.Tensor, M: int, H: int):
+        """(mean, var, count) the BatchNorm normalises with.  Training: the batch's (biased variance), over the rows of ALL ranks when a
+        process group is up (SyncBatchNorm), and the running statistics move (momentum 0.1, unbiased variance).  Eval: the running ones."""
+        import torch.distributed as dist
+        if not self.training:
+            return bn.running_mean, bn.running_var, float(M)
+        if M < 2:
+            raise HctError("BatchNorm1d in training mode needs more than one row")
+        mean, var = torch.empty(H, device=u.device), torch.empty(H, device=u.device)
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if world == 1:
+            _lib.check(lib.hct_batchnorm_stats(u.data_ptr(), M, H, float(bn.momentum), mean.data_ptr(), var.data_ptr(), bn.running_mean.data_ptr(),
+                                               bn.running_var.data_ptr(), _st()), "hct_batchnorm_stats")
+            bn.num_batches_tracked += 1
+            return mean, var, float(M)
+        # equal row counts on every rank (same batch size): global mean = mean of means, E[u^2] likewise (2 x H floats of glue)
+        _lib.check(lib.hct_batchnorm_stats(u.data_ptr(), M, H, 0.0, mean.data_ptr(), var.data_ptr(), None, None, _st()), "hct_batchnorm_stats")
+        both = torch.stack([mean, var + mean * mean])
+        dist.all_reduce(both)
+        both /= world
+        gmean, gvar = both[0], (both[1] - both[0] * both[0]).clamp_min_(0.0)
+        n = float(M * world)
+        with torch.no_grad():
+            bn.running_mean.mul_(1 - bn.momentum).add_(gmean, alpha=bn.momentum)
+            bn.running_var.mul_(1 - bn.momentum).add_(gvar * (n / (n - 1)), alpha=bn.momentum)
+            bn.num_batches_tracked += 1
+        return gmean.contiguous(), gvar.contiguous(), n
+
+    def _bn_backward(self, lib, bn, dh: torch.Tensor, saved, M: int, H: int, du: torch.Tensor, gv) -> None:
+        """dh = gradient wrt the GELU's output -> du = gradient wrt the Linear's output; the BatchNorm's weight / bias gradients."""
+        import torch.distributed as dist
+        xhat, dact, var, count = saved
+        name = next(f"mlp.{i}" for i in self._bn if self.mlp[i] is bn)
+        sums = torch.empty(2, H, device=dh.device)
+        _lib.check(lib.hct_bn_gelu_bwd_sums(dh.data_ptr(), _code(dh), dact.data_ptr(), xhat.data_ptr(), M, H, sums.data_ptr(), _st()), "hct_bn_gelu_bwd_sums")
+        gv(name + ".bias").copy_(sums[0])    # this rank's rows: the data-parallel gradient mean adds the other ranks'
+        gv(name + ".weight").copy_(sums[1])
+        if count > M:  # statistics shared over the ranks: so are the two sums that enter du
+            dist.all_reduce(sums)
+        _lib.check(lib.hct_bn_gelu_bwd_apply(dh.data_ptr(), _code(dh), dact.data_ptr(), xhat.data_ptr(), bn.weight.data_ptr(), var.data_ptr(), float(bn.eps),
+                                             sums.data_ptr(), float(count), M, H, du.data_ptr(), _code(du), _st()), "hct_bn_gelu_bwd_apply")
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:

@@ -273,6 +273,19 @@ int hct_ema_update(float* momentum_params, const float* params, int64_t n, doubl
 /* DINOHead tail (src/models/dino_head.py:37-41): rows L2-normalised (F.normalize, eps 1e-12), prototype weights weight-normalised
  * (torch.nn.utils.weight_norm, dim 0: W[k,:] = g[k] v[k,:] / ||v[k,:]||); forward keeps 1 / norm per row for the backward. */
 int hct_l2norm_rows_fwd(const float* z, int M, int n, void* zn, int zn_dtype, float* inv_norm, void* stream);
+/* Projection head with use_bn (dino_head.py:15-21, the default of config.py:86): Linear -> BatchNorm1d -> GELU.  u [M, D] fp32 is the
+ * Linear's output, mean / var [D] the statistics to normalise with -- hct_batchnorm_stats of u in training (the caller all-reduces
+ * them under data parallelism, as the SyncBatchNorm of main_pretrain_dino.py:183-185 does), the running ones in eval:
+ *   fwd   : xhat = (u - mean) / sqrt(var + eps); h = gelu(gamma * xhat + beta) in h_dtype; xhat and dact = gelu'(.) fp32 kept for the
+ *           backward (either may be NULL)
+ *   sums  : sums[0..D) = sum_rows dh * dact (= dbeta), sums[D..2D) = sum_rows dh * dact * xhat (= dgamma) of this rank's rows
+ *   apply : du = gamma / sqrt(var + eps) * (dh * dact - sums[0] / count - xhat * sums[1] / count), count = rows that shared the
+ *           statistics (all ranks; `sums` all-reduced then), du in dh's dtype or fp32                                          */
+int hct_bn_gelu_fwd(const float* u, const float* mean, const float* var, const float* gamma, const float* beta, float eps, int M, int D, void* h,
+                    int h_dtype, float* xhat, float* dact, void* stream);
+int hct_bn_gelu_bwd_sums(const void* dh, int dh_dtype, const float* dact, const float* xhat, int M, int D, float* sums, void* stream);
+int hct_bn_gelu_bwd_apply(const void* dh, int dh_dtype, const float* dact, const float* xhat, const float* gamma, const float* var, float eps,
+                          const float* sums, double count, int M, int D, void* du, int du_dtype, void* stream);
 int hct_l2norm_rows_bwd(const float* dzn, const void* zn, int zn_dtype, const float* inv_norm, int M, int n, float* dz, void* stream);
 int hct_weight_norm_fwd(const float* v, const float* g, int K, int n, void* w, int w_dtype, float* inv_norm, void* stream);
 int hct_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* inv_norm, int K, int n, float* dv, float* dg /* or NULL */,

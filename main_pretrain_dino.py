@@ -63,8 +63,6 @@ def parse_option():
 def build_pair(config, device):
     """MultiCropWrapper(ViTBackbone, DINOHead) from the VIT.* / DINO.* blocks (main_pretrain_dino.py:107-172)."""
     v, d = config.VIT, config.DINO
-    if d.USE_BN:
-        raise NotImplementedError("DINO.USE_BN True (BatchNorm in the projection head) is not built; the reference yaml uses False")
     backbone = ViTBackbone(in_chans=v.IN_CHANS, img_size=v.INPUT_SIZE, patch_size=v.PATCH_SIZE, hidden_size=v.HIDDEN_SIZE, mlp_dim=v.MLP_DIM,
                            num_layers=v.NUM_LAYERS, num_heads=v.NUM_HEADS, patch_embed=v.PATCH_EMBED, pos_embed=v.POS_EMBED,
                            classification=v.CLASSIFICATION, num_classes=config.DATA.NUM_CLASSES, dropout_rate=v.DROPOUT_RATE,

@@ -479,6 +479,47 @@ def dino_fixture():
                        requires_grad={n: bool(prm.requires_grad) for n, prm in head.named_parameters()},
                        y=sample(y, 256), dx=sample(xh.grad, 256),
                        grads={n: sample(prm.grad, 128) for n, prm in head.named_parameters() if prm.grad is not None})
+    # the same head with use_bn=True (the default of config.py:86), training mode: batch statistics, running statistics after one
+    # forward, gradients of every parameter incl. the BatchNorm affine pairs; then the eval-mode output with those running statistics
+    hb = DINOHead(48, 128, use_bn=True, norm_last_layer=True, nlayers=3, hidden_dim=64, bottleneck_dim=32)
+    for i, (n, prm) in enumerate(hb.named_parameters()):
+        if n.endswith("weight_g"):
+            continue
+        lo, hi = (-0.2, 0.2) if prm.dim() > 1 else ((0.5, 1.5) if n in ("mlp.1.weight", "mlp.4.weight") else (-0.05, 0.05))
+        prm.data.copy_(u(tuple(prm.shape), 560 + i, lo, hi))
+    hbp = {n: t.detach().clone() for n, t in hb.state_dict().items()}
+    xb = u((10, 48), 590, -1, 1).requires_grad_(True)
+    dyb = u((10, 128), 591, -1, 1)
+    hb.train()
+    yb = hb(xb)
+    (yb * dyb).sum().backward()
+    after = {n: t.detach().clone() for n, t in hb.state_dict().items()}
+    po = {n: (t.clone().float().requires_grad_(True) if (t.is_floating_point() and "running" not in n and not n.endswith("weight_g")) else t.clone()) for n, t in hbp.items()}
+    xo = xb.detach().clone().requires_grad_(True)
+    yo = D.dino_head_forward(po, xo, training=True)
+    (yo * dyb).sum().backward()
+    assert torch.allclose(yo, yb, rtol=1e-5, atol=1e-6), float((yo - yb).abs().max())
+    assert float((xo.grad - xb.grad).norm() / xb.grad.norm()) < 2e-5, float((xo.grad - xb.grad).norm() / xb.grad.norm())
+    for n, prm in hb.named_parameters():
+        if prm.grad is None:
+            continue
+        if n in ("mlp.0.bias", "mlp.3.bias"):  # a bias in front of a BatchNorm has a mathematically zero gradient (the mean is removed): round-off only
+            assert float(prm.grad.abs().max()) < 1e-5 and float(po[n].grad.abs().max()) < 1e-5, n
+        else:
+            assert float((po[n].grad - prm.grad).norm() / (prm.grad.norm() + 1e-30)) < 2e-5, n
+    for n in ("mlp.1.running_mean", "mlp.1.running_var", "mlp.4.running_mean", "mlp.4.running_var"):
+        assert torch.allclose(po[n], after[n], rtol=1e-5, atol=1e-7), n
+    hb.eval()
+    with torch.no_grad():
+        ye = hb(xb.detach())
+    ye_o = D.dino_head_forward({n: t.detach() for n, t in po.items()}, xb.detach(), training=False)
+    assert torch.allclose(ye_o, ye, rtol=1e-5, atol=1e-6)
+    out["head_bn"] = dict(in_dim=48, out_dim=128, hidden=64, bottleneck=32, keys=list(hbp.keys()), shapes={n: list(t.shape) for n, t in hbp.items()},
+                          param_seed0=560, bn_weight_range=[0.5, 1.5], x_seed=590, dy_seed=591, rows=10,
+                          y=sample(yb, 256), dx=sample(xb.grad, 256), y_eval=sample(ye, 256),
+                          grads={n: sample(prm.grad, 128) for n, prm in hb.named_parameters() if prm.grad is not None},
+                          running_after={n: after[n].flatten().tolist() for n in after if "running" in n},
+                          num_batches_tracked=int(after["mlp.1.num_batches_tracked"]))
     # one whole DINO iteration with the reference's modules (engine_pretrain_dino.py:59-104: teacher on the two global crops,
     # student on all crops through MultiCropWrapper, DINOLoss, backward, last-layer gradients cancelled, centre update, momentum
     # teacher update), CPU, no AMP.  Four crops of 24^3 x 3 channels, patch 12, 4 register tokens, qkv bias, sincos table --

@@ -93,6 +93,51 @@ def _build_pair(fx, dev, dtype, which):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 6e-2)])
+def test_dino_head_with_batchnorm_vs_reference_fixture(lib, cuda, dtype, tol):
+    """DINOHead(use_bn=True) on the HIP path (Linear -> hct_batchnorm_stats + hct_bn_gelu_fwd -> ..., backward through
+    hct_bn_gelu_bwd_sums / _apply) against the reference module's own outputs (tests/golden/dino.json["head_bn"]) and the oracle:
+    state-dict keys, training output, input and parameter gradients, running statistics / num_batches_tracked after one forward,
+    eval-mode output.  fp32 1e-3 (north_star); bf16 storage 6e-2 (ten rows: the batch statistics of so few rows amplify the rounding of
+    the bf16 operands; the whole-step test above holds bf16 to 5e-2 on its larger batch)."""
+    from headct_foundation_amd.dino_model import DINOHead
+    fx = json.load(open(os.path.join(GOLDEN, "dino.json")))["head_bn"]
+    p = D.make_head_bn_params(fx)
+    head = DINOHead(fx["in_dim"], fx["out_dim"], use_bn=True, norm_last_layer=True, nlayers=3, hidden_dim=fx["hidden"], bottleneck_dim=fx["bottleneck"],
+                    compute_dtype=dtype)
+    assert list(head.state_dict().keys()) == fx["keys"]
+    head.load_state_dict(p, strict=True)
+    head = head.to(cuda).train()
+    x = _hu((fx["rows"], fx["in_dim"]), fx["x_seed"], -1, 1).to(cuda).requires_grad_(True)
+    dy = _hu((fx["rows"], fx["out_dim"]), fx["dy_seed"], -1, 1).to(cuda)
+    y = head(x)
+    (y.float() * dy).sum().backward()
+    torch.cuda.synchronize()
+    got, want, l2, l2w = sample_of(y.float(), fx["y"])
+    assert abs(l2 - l2w) < tol * l2w and float((got - want).norm() / want.norm()) < tol
+    got, want, l2, l2w = sample_of(x.grad.float(), fx["dx"])
+    assert float((got - want).norm() / want.norm()) < tol
+    gscale = max(e["l2"] for e in fx["grads"].values())
+    for n, e in fx["grads"].items():
+        g = dict(head.named_parameters())[n].grad
+        got, want, l2, l2w = sample_of(g.float(), e)
+        if n in ("mlp.0.bias", "mlp.3.bias"):  # mathematically zero (the BatchNorm removes the mean): round-off of the column sums
+            assert float(g.abs().max()) < (1e-4 if dtype == "fp32" else 5e-2) * gscale, n
+        else:
+            assert float((got - want).norm() / (want.norm() + 1e-30)) < tol, (n, float((got - want).norm() / (want.norm() + 1e-30)))
+    sd = head.state_dict()
+    for n, want in fx["running_after"].items():
+        assert torch.allclose(sd[n].cpu().flatten(), torch.tensor(want), rtol=tol, atol=tol * 1e-2), n
+    assert int(sd["mlp.1.num_batches_tracked"]) == fx["num_batches_tracked"] == int(sd["mlp.4.num_batches_tracked"])
+    head.eval()
+    with torch.no_grad():
+        ye = head(x.detach())
+    got, want, l2, l2w = sample_of(ye.float(), fx["y_eval"])
+    assert float((got - want).norm() / want.norm()) < tol
+    assert int(head.state_dict()["mlp.1.num_batches_tracked"]) == fx["num_batches_tracked"]  # eval does not move the statistics
+
+
+@pytest.mark.gpu
 def test_backbone_reads_crops_in_place(lib, cuda):
     """ViTBackbone on a list of equally shaped crops (hct_vit_forward_parts: patch rows gathered straight from each tensor) is
     bit-identical, forward and backward, to the same backbone on their concatenation (MultiCropWrapper's torch.cat,

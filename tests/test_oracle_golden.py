@@ -255,6 +255,38 @@ def test_dino_oracle_vs_reference_fixture():
     assert np.array_equal(wd_cosine_scheduler(S["base"], S["final"], S["epochs"], S["niter"], S["warmup_epochs"], S["start"]), np.array(S["values"]))
 
 
+def test_dino_head_with_batchnorm_oracle_vs_reference_fixture():
+    """DINOHead(use_bn=True) -- the default of config.py:86 -- restated in oracle/dino_oracle.py against the outputs of the reference's
+    own module (tests/golden/dino.json["head_bn"]): training-mode output, input gradient, every parameter gradient (the Linear
+    biases in front of a BatchNorm have a mathematically zero gradient), running statistics after one forward, eval-mode output."""
+    import json, os
+    from oracle import dino_oracle as D
+    from tests.util import GOLDEN, sample_of
+    fx = json.load(open(os.path.join(GOLDEN, "dino.json")))["head_bn"]
+    p = D.make_head_bn_params(fx)
+    assert list(p.keys()) == fx["keys"]
+    po = {n: (t.clone().requires_grad_(True) if (t.is_floating_point() and "running" not in n and not n.endswith("weight_g")) else t.clone()) for n, t in p.items()}
+    x = _hu((fx["rows"], fx["in_dim"]), fx["x_seed"], -1, 1).requires_grad_(True)
+    dy = _hu((fx["rows"], fx["out_dim"]), fx["dy_seed"], -1, 1)
+    y = D.dino_head_forward(po, x, training=True)
+    (y * dy).sum().backward()
+    got, want, l2, l2w = sample_of(y, fx["y"])
+    assert abs(l2 - l2w) < 1e-5 * l2w and torch.allclose(got, want, rtol=1e-4, atol=1e-6)
+    got, want, l2, l2w = sample_of(x.grad, fx["dx"])
+    assert abs(l2 - l2w) < 1e-4 * l2w
+    for n, e in fx["grads"].items():
+        got, want, l2, l2w = sample_of(po[n].grad, e)
+        if n in ("mlp.0.bias", "mlp.3.bias"):
+            assert float(po[n].grad.abs().max()) < 1e-5 and l2w < 1e-4, n
+        else:
+            assert abs(l2 - l2w) < 1e-4 * l2w, n
+    for n, want in fx["running_after"].items():
+        assert torch.allclose(po[n].flatten(), torch.tensor(want), rtol=1e-5, atol=1e-7), n
+    ye = D.dino_head_forward({n: t.detach() for n, t in po.items()}, x.detach(), training=False)
+    got, want, l2, l2w = sample_of(ye, fx["y_eval"])
+    assert abs(l2 - l2w) < 1e-5 * l2w and torch.allclose(got, want, rtol=1e-4, atol=1e-6)
+
+
 def test_gaussian_smoothing_restatement_properties():
     """RandGaussianSmoothd restatement (transforms.py:230-238; MONAI absent, so pinned by properties only): kernel length and mass
     per sigma, separability (three 1-D passes == one dense 3-D correlation with the outer-product kernel), zero padding, samples
