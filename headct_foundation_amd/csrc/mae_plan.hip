@@ -293,7 +293,10 @@ int linear_wgrad(hct_mae_plan* p, const void* dY, const void* X, int M, int N, i
   a.B = X; a.b_dtype = p->dt; a.ldb = K; a.transB = 0;
   a.C = p->gf(w); a.c_dtype = HCT_F32; a.ldc = K;
   int rc = 0;
-  if (p->wg_defer && tn_group_ok(&a)) {
+  // (a reduction of more than 4096 stages stays on the split-K launch: the workgroups of a window sweep a whole-tile reduction
+  //  without meeting again, and over 10 000 stages -- DINO at 640 crops x 517 tokens -- they drift out of the L2's reach of each
+  //  other: 281.9 against 278.4 ms per DINO iteration, where the MAE configurations gain 1.1 - 1.5 ms)
+  if (p->wg_defer && M <= 131072 && tn_group_ok(&a)) {
     p->wg_pending.push_back(a);  // runs with the next grouped launch (flush_wgrads); dY and X stay untouched until then
   } else {
     a.workspace_armed = p->gemm_ws_armed ? 1 : 0;  // s_gemm is this plan's alone: its fold counters are reset by the first wgrad after a bind
