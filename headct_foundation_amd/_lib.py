@@ -148,6 +148,7 @@ _PROTOS = {
     "hct_mae_plan_workspace_bytes": (c_size_t, [c_void_p]),
     "hct_mae_plan_len_keep": (c_int, [c_void_p]),
     "hct_mae_plan_set_tail": (c_int, [c_void_p, c_int]),
+    "hct_mae_plan_set_dec0": (c_int, [c_void_p, c_int]),
     "hct_mae_backward_final_offset": (c_int64, [c_void_p]),
     "hct_mae_plan_set_wgrad_defer": (c_int, [c_void_p, c_int, c_int]),
     "hct_mae_plan_bind": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),

@@ -41,6 +41,12 @@ int check_hip(hipError_t e, const char* what);
 int masked_mse_launch(const void* pred, int pred_dtype, const void* x, int x_dtype, const float* mask, int B, int C, int S, int P,
                       int norm_pix, float mask_sum, float* row_loss, float* loss, void* dpred, const float* dpred_scale,
                       float host_scale, hipStream_t s, const int32_t* masked_ids = nullptr, int K = 0);  // masked_ids: compact-row form
+// first decoder block on the "cat" rows (kept tokens + one table row per patch position; elementwise.hip, used by mae_plan.hip)
+int dec0_index(const int32_t* ids_restore, int B, int L, int K, int32_t* kept_rows, int32_t* cat_idx, hipStream_t s);
+int dec0_table(const float* mask_token, const float* pos, int L, int D, float* out, hipStream_t s);
+int dec0_aggregate(const void* g, int dtype, const int32_t* kept_rows, const int32_t* ids_restore, int B, int L, int K, int W, void* out, hipStream_t s);
+int dec0_token_grads(const float* dh, const int32_t* ids_shuffle, const float* dcat, int B, int L, int K, int D, float* dmask, float* dcls,
+                     void* workspace, size_t workspace_bytes, hipStream_t s);
 // host-side test: can this product join a grouped weight-gradient launch (hct_gemm_tn_group_*; gemm.hip)
 bool tn_group_ok(const hct_gemm_args* a);
 // buf[i] *= *scale unless *scale == 1 (every block then leaves after one scalar load)

@@ -950,6 +950,101 @@ __global__ void __launch_bounds__(256) gather_rows16_kernel(const uint4* __restr
   }
 }
 
+// ---- first decoder block: the masked tokens' input is mask_token + pos[l] for every volume (mae.py:259-265), so LayerNorm and
+// the qkv Linear of THAT block need them once per position, not once per (volume, position) ----------------------------------
+// rows of the "cat" matrices: c < Nc = B (K+1): class token + kept patches of volume b in shuffle order (the layout of the
+// decoder_embed output); c = Nc + l: the table row of patch position l.
+//   kept_rows[c]  (length Nc + L): decoder row b (L+1) + t of compact row c, -1 for the table rows
+//   cat_idx[r]    (length B (L+1)): cat row that holds decoder row r's LayerNorm / qkv values
+__global__ void __launch_bounds__(256) dec0_index_kernel(const int32_t* __restrict__ ids_restore, int B, int L, int K,
+                                                         int32_t* __restrict__ kept_rows, int32_t* __restrict__ cat_idx) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  const int Nc = B * (K + 1);
+  if (r < L) kept_rows[Nc + r] = -1;
+  if (r >= B * (L + 1)) return;
+  const int b = r / (L + 1), t = r - b * (L + 1);
+  int c;
+  if (t == 0) c = b * (K + 1);
+  else {
+    const int rank = ids_restore[(size_t)b * L + (t - 1)];
+    c = rank < K ? b * (K + 1) + 1 + rank : Nc + (t - 1);
+  }
+  if (c < Nc) kept_rows[c] = r;
+  cat_idx[r] = c;
+}
+
+__global__ void __launch_bounds__(256) dec0_table_kernel(const float* __restrict__ mask_token, const float* __restrict__ pos, int D,
+                                                         float* __restrict__ out) {  // out[l] = mask_token + pos[l]
+  const int l = blockIdx.x;
+  for (int d = threadIdx.x * 4; d < D; d += 1024)
+    Vec4<float>::store(out + (size_t)l * D + d, Vec4<float>::load(mask_token + d) + Vec4<float>::load(pos + (size_t)l * D + d));
+}
+
+// table rows of the cat gradient from the full [B (L+1), W] gradient: out[l] = sum over the volumes that masked position l of
+// g[b (L+1) + 1 + l].  One block per (position, 256 columns): 64 column quads x 4 volume groups, 8 row loads in flight per thread,
+// the four groups' sums added in group order (fixed summation order).  (The kept rows are a plain row gather.)
+template <typename T>
+__global__ void __launch_bounds__(256) dec0_table_sum_kernel(const T* __restrict__ g, const int32_t* __restrict__ ids_restore, int B, int L, int K,
+                                                             int W, T* __restrict__ out) {
+  __shared__ f32x4 s_part[4][64];
+  const int l = blockIdx.x, q = threadIdx.x & 63, vg = threadIdx.x >> 6;
+  const int col = blockIdx.y * 256 + q * 4;
+  f32x4 acc = {0, 0, 0, 0};
+  if (col < W) {
+    for (int b0 = vg; b0 < B; b0 += 32) {
+      int rk[8];
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rk[u] = b0 + 4 * u < B ? ids_restore[(size_t)(b0 + 4 * u) * L + l] : -1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = rk[u] >= K ? Vec4<T>::load(g + ((size_t)(b0 + 4 * u) * (L + 1) + 1 + l) * W + col) : f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+  }
+  s_part[vg][q] = acc;
+  __syncthreads();
+  if (vg == 0 && col < W) Vec4<T>::store(out + (size_t)l * W + col, (s_part[0][q] + s_part[1][q]) + (s_part[2][q] + s_part[3][q]));
+}
+
+// dmask_token[d] = sum_blk partial[blk][0][d] (masked rows of the residual gradient, decoder_assemble_bwd_reduce_kernel)
+//                + sum_l dcat[Nc + l][d] (the table rows' LayerNorm gradient);   ddec_cls[d] = sum_b dcat[b (K+1)][d]
+// 512 threads = 32 columns x 16 row groups, 8 loads in flight per thread, fixed order.
+__global__ void __launch_bounds__(512) dec0_token_grads_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ dcat,
+                                                               int B, int L, int K, int D, float* __restrict__ dmask, float* __restrict__ dcls) {
+  __shared__ float s_m[16][32], s_c[16][32];
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + c;
+  const size_t Nc = (size_t)B * (K + 1);
+  auto sum_rows = [&](const float* base, int n, size_t stride) {
+    float acc = 0.f;
+    for (int r0 = rg; r0 < n; r0 += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = r0 + 16 * u < n ? base[(size_t)(r0 + 16 * u) * stride + d] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    return acc;
+  };
+  float m = 0.f, cl = 0.f;
+  if (d < D) {
+    m = sum_rows(partial, nblk, (size_t)2 * D) + sum_rows(dcat + Nc * D, L, D);
+    cl = sum_rows(dcat, B, (size_t)(K + 1) * D);
+  }
+  s_m[rg][c] = m;
+  s_c[rg][c] = cl;
+  __syncthreads();
+  if (rg == 0 && d < D) {
+    float a = 0.f, bsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a += s_m[i][c]; bsum += s_c[i][c]; }
+    dmask[d] = a;
+    dcls[d] = bsum;
+  }
+}
+
 int scale_unless_one(void* buf, int dtype, int64_t n, const float* scale, hipStream_t s) {
   HCT_REQUIRE(n % 4 == 0 && scale, "scale_unless_one: n %% 4 != 0 or null scale");
   const int blocks = (int)std::min<int64_t>(2048, (n / 4 + 255) / 256);
@@ -980,6 +1075,43 @@ int masked_mse_launch(const void* pred, int pred_dtype, const void* x, int x_dty
                                         C, S, P, L, norm_pix, inv, loss ? row_loss : nullptr, (T*)dpred, dpred_scale, host_scale, masked_ids, K));
   if (loss) hipLaunchKernelGGL(loss_fold_kernel, dim3(1), dim3(256), 0, s, row_loss, masked_ids ? B * (L - K) : B * L, inv, loss);
   HCT_CHECK_LAUNCH("hct_masked_mse");
+  return 0;
+}
+
+int dec0_index(const int32_t* ids_restore, int B, int L, int K, int32_t* kept_rows, int32_t* cat_idx, hipStream_t s) {
+  const int n = std::max(B * (L + 1), L);
+  hipLaunchKernelGGL(dec0_index_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ids_restore, B, L, K, kept_rows, cat_idx);
+  HCT_CHECK_LAUNCH("dec0_index");
+  return 0;
+}
+int dec0_table(const float* mask_token, const float* pos, int L, int D, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(dec0_table_kernel, dim3(L), dim3(256), 0, s, mask_token, pos, D, out);
+  HCT_CHECK_LAUNCH("dec0_table");
+  return 0;
+}
+int dec0_aggregate(const void* g, int dtype, const int32_t* kept_rows, const int32_t* ids_restore, int B, int L, int K, int W, void* out, hipStream_t s) {
+  HCT_REQUIRE(W % 4 == 0 && (W * dtype_size(dtype)) % 16 == 0, "dec0_aggregate: row width must be a multiple of 16 bytes");
+  const int Nc = B * (K + 1);
+  if (int rc = hct_gather_rows(g, kept_rows, Nc, (int)(W * dtype_size(dtype)), out, s)) return rc;  // kept / class rows: copies
+  const dim3 grid(L, (W + 255) / 256);
+  HCT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(dec0_table_sum_kernel<T>, grid, dim3(256), 0, s, (const T*)g, ids_restore, B, L, K, W, (T*)out + (size_t)Nc * W));
+  HCT_CHECK_LAUNCH("dec0_aggregate");
+  return 0;
+}
+// masked-token / class-token gradients of the decoder input when the first block ran through the cat matrices: the masked rows of
+// the residual gradient `dh` are reduced as in hct_decoder_assemble_bwd, the LayerNorm part comes from `dcat`
+int dec0_token_grads(const float* dh, const int32_t* ids_shuffle, const float* dcat, int B, int L, int K, int D, float* dmask, float* dcls,
+                     void* workspace, size_t workspace_bytes, hipStream_t s) {
+  if (workspace_bytes < hct_assemble_bwd_workspace_bytes(D)) {
+    set_error("dec0_token_grads: workspace too small");
+    return HCT_E_WORKSPACE;
+  }
+  const int threads = D / 4 >= 256 ? 256 : (D / 4 > 64 ? 128 : 64);
+  const int nblk = std::min(B, kAsmBlocks);
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(decoder_assemble_bwd_reduce_kernel, dim3(nblk), dim3(threads), 0, s, dh, ids_shuffle, B, L, K, D, partial);
+  hipLaunchKernelGGL(dec0_token_grads_kernel, dim3((D + 31) / 32), dim3(512), 0, s, partial, nblk, dcat, B, L, K, D, dmask, dcls);
+  HCT_CHECK_LAUNCH("dec0_token_grads");
   return 0;
 }
 }  // namespace hct

@@ -68,6 +68,13 @@ struct hct_mae_plan {
   bool tail_ok = false;   // the geometry allows it
   int Mc = 0;
   size_t a_tail_rows = 0, a_tail_inv = 0, a_oc = 0, s_dhc = 0;
+  // First decoder block on "cat" rows (hct_mae_plan_set_dec0): its masked tokens enter as mask_token + pos[l] in EVERY volume
+  // (mae.py:259-265), so LayerNorm1 and the qkv Linear of that block -- forward, weight gradient, input gradient, LayerNorm backward --
+  // need one row per patch position for them, not one per (volume, position): Rcat = B (K+1) kept / class rows + L table rows
+  // instead of B (L+1).
+  bool dec0 = false, dec0_fwd = false, dec0_ok = false;
+  int Rcat = 0;
+  size_t a_kept_rows = 0, a_cat_idx = 0, a_hk = 0, a_x1c = 0, a_mean_c = 0, a_rstd_c = 0, a_qkv_cat = 0, a_dqkv_cat = 0, a_dcat = 0;
   std::vector<size_t> h_enc, h_dec;  // fp32 residual-stream chain
   std::vector<BlockA> aenc, adec;
   size_t s_dh, s_dh_shadow, s_dbig, s_dx, s_do, s_dqkv, s_small, s_small_bytes, s_gemm, s_gemm_bytes, s_nt_bytes = 0;
@@ -434,6 +441,68 @@ int block_backward(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const Bl
   return fold_flush(sink, s);
 }
 
+// First decoder block on cat rows (see hct_mae_plan::dec0).  Forward: LayerNorm1 + qkv on the Rcat rows, the full qkv matrix that
+// the attention reads is assembled from them (a row gather); everything behind the attention as block_forward.
+int block_forward_dec0(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const float* h_in, float* h_out, hipStream_t s) {
+  const int B = p->B, N = p->Nd, d = p->Dd, m = p->Mlpd, heads = p->Hd, M = B * N, Rc = p->Rcat, Nc = p->Me;
+  unsigned char* ws = p->ws;
+  const int32_t* kept = (const int32_t*)(ws + p->a_kept_rows);
+  float* hk = (float*)(ws + p->a_hk);
+  RC(hct_gather_rows(h_in, kept, Nc, d * 4, hk, s));
+  RC(dec0_table(p->pf(p->p_mask), p->pf(p->p_dpos), p->L, d, hk + (size_t)Nc * d, s));
+  RC(hct_layernorm_fwd(hk, p->pf(bp.ln1_w), p->pf(bp.ln1_b), Rc, d, 1e-5f, ws + p->a_x1c, p->dt, (float*)(ws + p->a_mean_c), (float*)(ws + p->a_rstd_c), s));
+  RC(linear_fwd(p, ws + p->a_x1c, Rc, d, bp.qkv_w, bp.qkv_b, 3 * d, ws + p->a_qkv_cat, p->dt, HCT_ACT_NONE, nullptr, nullptr, s));
+  RC(hct_gather_rows(ws + p->a_qkv_cat, (const int32_t*)(ws + p->a_cat_idx), M, (int)(3 * d * p->esz()), ws + ba.qkv, s));
+  RC(hct_attention_fwd(ws + ba.qkv, B, N, heads, d / heads, p->dt, ws + ba.o, (float*)(ws + ba.lse), s));
+  RC(linear_fwd(p, ws + ba.o, M, d, bp.proj_w, bp.proj_b, d, ws + ba.h_mid, HCT_F32, HCT_ACT_NONE, nullptr, h_in, s));
+  RC(hct_layernorm_fwd((const float*)(ws + ba.h_mid), p->pf(bp.ln2_w), p->pf(bp.ln2_b), M, d, 1e-5f, ws + ba.x2, p->dt, (float*)(ws + ba.mean2), (float*)(ws + ba.rstd2), s));
+  RC(linear_fwd(p, ws + ba.x2, M, d, bp.fc1_w, bp.fc1_b, m, ws + ba.g, p->dt, kActFc1, ws + ba.u, nullptr, s));
+  RC(linear_fwd(p, ws + ba.g, M, m, bp.fc2_w, bp.fc2_b, d, h_out, HCT_F32, HCT_ACT_NONE, nullptr, (const float*)(ws + ba.h_mid), s));
+  return 0;
+}
+
+// Its backward: as block_backward down to the attention; the qkv gradient is then reduced to cat rows (kept rows copied, the masked
+// rows summed per patch position: weight gradient, input gradient and LayerNorm backward are linear in it for a fixed row input), and
+// the LayerNorm backward leaves the gradient wrt the kept / class rows of the decoder input in `a_dcat` (fp32) and `a_de` (compute
+// dtype = the operand of decoder_embed's backward), the table rows' part behind them.  The residual gradient `s_dh` keeps the part of
+// the masked rows that does not pass through LayerNorm1 (dec0_token_grads sums it).
+int block_backward_dec0(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const BlockG& bg, hipStream_t s) {
+  const int B = p->B, N = p->Nd, d = p->Dd, m = p->Mlpd, heads = p->Hd, M = B * N, Rc = p->Rcat;
+  unsigned char* ws = p->ws;
+  float* dh = (float*)(ws + p->s_dh);
+  void* dhs = ws + bg.out;
+  void* dhs_mid = ws + bg.mid;
+  void* dbig = ws + bg.big;
+  void* dx = ws + p->s_dx;
+  void* d_o = ws + p->s_do;
+  void* dqkv = ws + bg.qkv;
+  const int32_t* kept = (const int32_t*)(ws + p->a_kept_rows);
+  FoldSink sink;
+  struct SinkScope {
+    FoldSink* prev;
+    explicit SinkScope(FoldSink* s_) : prev(g_fold_sink) { g_fold_sink = s_; }
+    ~SinkScope() { g_fold_sink = prev; }
+  } scope(defer_folds() ? &sink : g_fold_sink);
+  RC(linear_wgrad(p, dhs, ws + ba.g, M, d, m, bp.fc2_w, -1, s));
+  RC(linear_dgrad(p, dhs, M, d, bp.fc2_w, m, dbig, kActFc2Dgrad, ws + ba.u, s, p->gf(bp.fc1_b)));
+  RC(linear_wgrad(p, dbig, ws + ba.x2, M, m, d, bp.fc1_w, -1, s));
+  RC(linear_dgrad(p, dbig, M, m, bp.fc1_w, d, dx, HCT_ACT_NONE, nullptr, s));
+  RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + ba.h_mid), (const float*)(ws + ba.mean2), (const float*)(ws + ba.rstd2),
+                       p->pf(bp.ln2_w), dh, M, d, dh, dhs_mid, p->dt, p->gf(bp.ln2_w), p->gf(bp.ln2_b), p->gf(bp.proj_b), ws + p->s_fold_a,
+                       p->s_fold_bytes, s));
+  RC(linear_wgrad(p, dhs_mid, ws + ba.o, M, d, d, bp.proj_w, -1, s));
+  RC(linear_dgrad(p, dhs_mid, M, d, bp.proj_w, d, d_o, HCT_ACT_NONE, nullptr, s));
+  RC(hct_attention_bwd(ws + ba.qkv, ws + ba.o, d_o, (const float*)(ws + ba.lse), B, N, heads, d / heads, p->dt, dqkv, s));
+  if (bp.qkv_b >= 0) RC(hct_colsum(dqkv, p->dt, M, 3 * d, 3 * d, p->gf(bp.qkv_b), ws + p->s_small2, p->s_small2_bytes, s));  // bias: every row
+  RC(dec0_aggregate(dqkv, p->dt, kept, (const int32_t*)(ws + p->a_ids_restore), B, p->L, p->K, 3 * d, ws + p->a_dqkv_cat, s));
+  RC(linear_wgrad(p, ws + p->a_dqkv_cat, ws + p->a_x1c, Rc, 3 * d, d, bp.qkv_w, -1, s));
+  RC(linear_dgrad(p, ws + p->a_dqkv_cat, Rc, 3 * d, bp.qkv_w, d, dx, HCT_ACT_NONE, nullptr, s));
+  RC(hct_layernorm_bwd_mapped(dx, p->dt, (const float*)(ws + p->a_hk), (const float*)(ws + p->a_mean_c), (const float*)(ws + p->a_rstd_c),
+                              p->pf(bp.ln1_w), dh, kept, Rc, d, (float*)(ws + p->a_dcat), ws + p->a_de, p->dt, p->gf(bp.ln1_w), p->gf(bp.ln1_b),
+                              nullptr, ws + p->s_fold_b, p->s_fold_bytes, s));
+  return fold_flush(sink, s);
+}
+
 // Last decoder block in compact-tail mode: LN1 / qkv / attention on every row, then the masked patches' rows of the attention
 // output and of the residual stream are gathered (tail_rows) and proj / LN2 / MLP run on Mc rows.  h_out_c [Mc, d].
 int block_forward_tail(hct_mae_plan* p, const BlockP& bp, const BlockA& ba, const float* h_in, float* h_out_c, hipStream_t s) {
@@ -624,7 +693,23 @@ hct_mae_plan* hct_mae_plan_create(const hct_mae_config* c, int batch, int comput
   };
   alloc_ring(p->genc, c->encoder_depth, Me, D, (size_t)p->Mlp);
   alloc_ring(p->gdec, p->cfg.decoder_depth, Md, Dd, (size_t)p->Mlpd);
-  p->a_de = w.take(Me * Dd * es);
+  p->Rcat = p->vit ? 0 : (int)(Me + L);
+  p->dec0_ok = !p->vit && p->cfg.decoder_depth >= 2 && (Dd * es) % 16 == 0 && (3 * Dd * es) % 16 == 0;
+  {
+    const char* ev = getenv("HCT_DEC0_TABLE");
+    p->dec0 = p->dec0_ok && !(ev && ev[0] == '0');
+    const size_t Rc = (size_t)p->Rcat;
+    p->a_kept_rows = w.take(Rc * 4);
+    p->a_cat_idx = w.take(Md * 4);
+    p->a_hk = w.take(Rc * Dd * 4);
+    p->a_x1c = w.take(Rc * Dd * es);
+    p->a_mean_c = w.take(Rc * 4);
+    p->a_rstd_c = w.take(Rc * 4);
+    p->a_qkv_cat = w.take(Rc * 3 * Dd * es);
+    p->a_dqkv_cat = w.take(Rc * 3 * Dd * es);
+    p->a_dcat = w.take(Rc * Dd * 4);
+  }
+  p->a_de = w.take((Me + L) * Dd * es);  // (+ L rows: the table rows' part of the cat gradient's shadow)
   p->a_dtok = w.take(B * K * D * es);
   size_t small = hct_layernorm_bwd_workspace_bytes((int)Mx, (int)Dx);
   small = std::max(small, hct_assemble_bwd_workspace_bytes((int)Dx));
@@ -701,6 +786,11 @@ int64_t hct_mae_plan_param_elems(const hct_mae_plan* p) { return p->param_elems;
 int64_t hct_mae_plan_bf16_t_elems(const hct_mae_plan* p) { return p->bf16t_elems; }
 size_t hct_mae_plan_workspace_bytes(const hct_mae_plan* p) { return p->ws_bytes; }
 int hct_mae_plan_len_keep(const hct_mae_plan* p) { return p ? p->K : -1; }
+int hct_mae_plan_set_dec0(hct_mae_plan* p, int on) {
+  if (!p) return -1;
+  p->dec0 = on != 0 && p->dec0_ok;
+  return p->dec0 ? 1 : 0;
+}
 int hct_mae_plan_set_tail(hct_mae_plan* p, int compact) {
   if (!p) return -1;
   p->tail = compact != 0 && p->tail_ok;
@@ -773,8 +863,13 @@ int hct_mae_forward(hct_mae_plan* p, const void* x, int x_dtype, const float* no
   const bool tail = p->tail && p->tail_ok;
   p->tail_fwd = tail;
   if (tail) RC(hct_tail_rows(ids_restore, B, p->L, p->K, (int32_t*)(ws + p->a_tail_rows), (int32_t*)(ws + p->a_tail_inv), s));
+  const bool dec0 = p->dec0 && p->dec0_ok;
+  p->dec0_fwd = dec0;
+  if (dec0) RC(dec0_index(ids_restore, B, p->L, p->K, (int32_t*)(ws + p->a_kept_rows), (int32_t*)(ws + p->a_cat_idx), s));
   for (int i = 0; i < c.decoder_depth; ++i) {
-    if (tail && i == c.decoder_depth - 1)
+    if (dec0 && i == 0)
+      RC(block_forward_dec0(p, p->dec[i], p->adec[i], (const float*)(ws + p->h_dec[i]), (float*)(ws + p->h_dec[i + 1]), s));
+    else if (tail && i == c.decoder_depth - 1)
       RC(block_forward_tail(p, p->dec[i], p->adec[i], (const float*)(ws + p->h_dec[i]), (float*)(ws + p->h_dec[i + 1]), s));
     else
       RC(block_forward(p, p->dec[i], p->adec[i], (const float*)(ws + p->h_dec[i]), (float*)(ws + p->h_dec[i + 1]), B, p->Nd, p->Dd, p->Mlpd, p->Hd, s));
@@ -914,7 +1009,9 @@ int hct_mae_backward_stage(hct_mae_plan* p, int stage, void* stream) {
   }
   if (stage <= nd) {
     const int i = nd - stage;
-    if (p->tail_fwd && i == nd - 1)
+    if (p->dec0_fwd && i == 0)
+      RC(block_backward_dec0(p, p->dec[i], p->adec[i], p->gdec[i % Rd], s));
+    else if (p->tail_fwd && i == nd - 1)
       RC(block_backward_tail(p, p->dec[i], p->adec[i], p->gdec[i % Rd], dec_out(i - 1), (const float*)(ws + p->h_dec[i]), i > 0 ? p->dec[i - 1].fc2_b : -1, s));
     else
       RC(block_backward(p, p->dec[i], p->adec[i], p->gdec[i % Rd], dec_out(i - 1), (const float*)(ws + p->h_dec[i]), B, p->Nd, p->Dd, p->Mlpd, p->Hd,
@@ -924,8 +1021,12 @@ int hct_mae_backward_stage(hct_mae_plan* p, int stage, void* stream) {
   if (stage == nd + 1) {  // decoder input assembly -> decoder_embed -> encoder norm
     void* de = ws + p->a_de;
     void* dhs = ws + enc_out(ne - 1);
-    RC(hct_decoder_assemble_bwd(dh, (const int32_t*)(ws + p->a_ids_restore), (const int32_t*)(ws + p->a_ids_shuffle), B, p->L, p->K, p->Dd, de,
-                                p->dt, p->gf(p->p_mask), p->gf(p->p_dcls), small, p->s_small_bytes, s));
+    if (p->dec0_fwd)  // the kept rows' gradient is in a_de already (block_backward_dec0); the two token gradients from its pieces
+      RC(dec0_token_grads(dh, (const int32_t*)(ws + p->a_ids_shuffle), (const float*)(ws + p->a_dcat), B, p->L, p->K, p->Dd, p->gf(p->p_mask),
+                          p->gf(p->p_dcls), small, p->s_small_bytes, s));
+    else
+      RC(hct_decoder_assemble_bwd(dh, (const int32_t*)(ws + p->a_ids_restore), (const int32_t*)(ws + p->a_ids_shuffle), B, p->L, p->K, p->Dd, de,
+                                  p->dt, p->gf(p->p_mask), p->gf(p->p_dcls), small, p->s_small_bytes, s));
     RC(linear_wgrad(p, de, ws + p->a_latent, p->Me, p->Dd, p->D, p->p_de_w, p->p_de_b, s));
     RC(linear_dgrad(p, de, p->Me, p->Dd, p->p_de_w, p->D, dx, HCT_ACT_NONE, nullptr, s));
     RC(hct_layernorm_bwd(dx, p->dt, (const float*)(ws + p->h_enc[ne]), (const float*)(ws + p->a_lat_mean), (const float*)(ws + p->a_lat_rstd),

@@ -147,6 +147,8 @@ class _MAEFunction(torch.autograd.Function):
         # a training forward needs no prediction for the kept patches (the loss drops them, mae.py:298-299): the decoder's tail
         # then runs on the masked patches' rows only, unless the caller asked for the full prediction (`full_pred`)
         plan.tail = bool(plan.lib.hct_mae_plan_set_tail(plan.handle, int(train and not getattr(model, "full_pred", False))) == 1)
+        if not getattr(model, "dec0_table", True):  # (testing: the first decoder block on every row instead of kept rows + one row per position)
+            plan.lib.hct_mae_plan_set_dec0(plan.handle, 0)
         # training forward: the loss pass also leaves d(loss)/d(pred) (scaled by 1/world under data parallelism) for the backward
         xdt = _lib.HCT_F16 if x.dtype == torch.float16 else HCT_F32
         _lib.check(plan.lib.hct_mae_forward(plan.handle, x.data_ptr(), xdt, noise.data_ptr(), plan.loss.data_ptr(),

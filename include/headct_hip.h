@@ -391,6 +391,12 @@ int hct_mae_plan_len_keep(const hct_mae_plan*);            /* visible patches pe
  * default) for a forward whose reconstruction of every patch is wanted.  Returns the mode in effect (0 where the geometry
  * does not allow it), < 0 on a null plan.                                                                                */
 int hct_mae_plan_set_tail(hct_mae_plan*, int compact);
+/* First decoder block on "cat" rows (default on for MAE plans with two or more decoder blocks; HCT_DEC0_TABLE=0 at plan creation or
+ * on = 0 here turns it off): the masked tokens enter the decoder as mask_token + pos[l] in every volume (mae.py:259-265), so
+ * LayerNorm1 and the qkv Linear of that block run on B*(K+1) kept / class rows + L table rows instead of B*(L+1), forward and
+ * backward; same loss, same gradients (the sums over the masked rows are taken per patch position first).  Returns the mode in
+ * effect. */
+int hct_mae_plan_set_dec0(hct_mae_plan*, int on);
 /* bind caller-owned device buffers. params_bf16 / params_bf16_t may be NULL in HCT_F32 mode. */
 int hct_mae_plan_bind(hct_mae_plan*, float* params, float* grads, void* params_bf16, void* params_bf16_t,
                       void* workspace, size_t workspace_bytes);

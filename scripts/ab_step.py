@@ -50,6 +50,9 @@ HOOKS = {
                  lambda: [lib.hct_mae_plan_set_wgrad_defer(pl.handle, 1, 0) for pl in model._plans.values()]),
     # on = two workgroups per CU (256 x 128 tiles) for the shapes with less than one round of 256 x 256 tiles (the encoder's 165)
     "w4small": (lambda: lib.hct_debug_set_gemm_variant(-10), lambda: lib.hct_debug_set_gemm_variant(-11)),
+    # on = the first decoder block's LayerNorm1 / qkv on kept rows + one row per patch position (the default), off = on every row
+    "dec0": (lambda: [lib.hct_mae_plan_set_dec0(pl.handle, 1) for pl in model._plans.values()],
+             lambda: [lib.hct_mae_plan_set_dec0(pl.handle, 0) for pl in model._plans.values()]),
     "evenrounds": (lambda: lib.hct_debug_set_gemm_variant(-12), lambda: lib.hct_debug_set_gemm_variant(-13)),
     "skgain12": (lambda: lib.hct_debug_set_gemm_variant(-100 - 12), lambda: lib.hct_debug_set_gemm_variant(-100 - 20)),
     "skgain16": (lambda: lib.hct_debug_set_gemm_variant(-100 - 16), lambda: lib.hct_debug_set_gemm_variant(-100 - 20)),

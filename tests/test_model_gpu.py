@@ -142,6 +142,43 @@ def test_compact_decoder_tail_vs_full_and_oracle(lib, cuda, name, batch, seed, d
         assert worst[0] < 1e-3, worst
 
 
+@pytest.mark.parametrize("name,batch,seed", [("micro2", 2, 0), ("tiny", 3, 1), ("yaml_cut2", 2, 1)])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_first_decoder_block_on_cat_rows_vs_every_row(lib, cuda, name, batch, seed, dtype):
+    """The masked tokens enter the decoder as mask_token + pos[l] in every volume (mae.py:259-265): the first decoder block's
+    LayerNorm1 / qkv run on the kept + class rows and ONE table row per patch position, forward and backward (weight gradient, input
+    gradient, LayerNorm backward, mask_token / decoder_cls_token gradients from the pieces).  Loss and every gradient must be those of
+    the run that pushes every row through (`dec0_table = False`): 1e-5 fp32; bf16 rounds the per-position sums once more (3e-3)."""
+    import dataclasses
+    # (micro / yaml_cut with a second decoder block: qkv bias and norm_pix_loss on the path; the path needs two decoder blocks)
+    cfg = dataclasses.replace(O.CONFIGS[name[:-1]], decoder_depth=2) if name.endswith("2") else O.CONFIGS[name]
+    assert cfg.decoder_depth >= 2
+    params = O.make_params(cfg, seed)
+    x, noise = O.make_volume(cfg, batch, seed), O.make_noise(cfg, batch, seed)
+    out = {}
+    for key in ("rows", "cat"):
+        m = build_hip_model(cfg, params, cuda, dtype, full_pred=False)
+        m.dec0_table = key == "cat"
+        m.train()
+        loss, _, _ = m(x.to(cuda), noise=noise.to(cuda))
+        loss.backward()
+        torch.cuda.synchronize()
+        out[key] = (float(loss), grads_by_name(m))
+    tol = 1e-5 if dtype == "fp32" else 3e-3
+    assert abs(out["cat"][0] - out["rows"][0]) <= tol * abs(out["rows"][0])
+    assert set(out["cat"][1]) == set(out["rows"][1])
+    for k, g in out["rows"][1].items():
+        if k.endswith("qkv.bias"):
+            assert (out["cat"][1][k] - g).abs().max() <= 1e-6 + tol * g.abs().max(), k
+        else:
+            assert rel_err(out["cat"][1][k], g) < tol, (k, rel_err(out["cat"][1][k], g))
+    if dtype == "fp32":
+        o_loss, _, _, o_grads, _ = O.forward_backward(cfg, params, x, noise)
+        assert abs(out["cat"][0] - float(o_loss)) / abs(float(o_loss)) < 1e-3
+        for k in ("mask_token", "decoder_cls_token", "decoder_blocks.0.attn.qkv.weight", "decoder_blocks.0.att_norm.weight", "decoder_embed.weight"):
+            assert rel_err(out["cat"][1][k], o_grads[k]) < 1e-3, k
+
+
 def test_train_curve_fp32_vs_golden(lib, cuda):
     """N-step loss curve, LR values and parameters after training vs the reference's own train_one_epoch."""
     from headct_foundation_amd.optim import HipAdamW, clip_gradients
