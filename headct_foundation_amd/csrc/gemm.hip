@@ -1251,13 +1251,10 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
 #pragma unroll
               for (int j = 0; j < 8; ++j) acc[i + u][j] += v[u][j];
           }
-          if (s_bad) {
-            const float nanv = __builtin_nanf("");
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-              for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{nanv, nanv, nanv, nanv};
-          }
+          // (one poisoned accumulator is enough -- four NaN outputs per lane reach the loss through every later layer -- and costs
+          //  no registers: filling all 32 accumulators under a branch made every stream-K instance spill, 112 - 192 B per lane; so did
+          //  a branch around one of them, hence the unconditional multiplication by 1 or NaN)
+          acc[0][0] = acc[0][0] * (s_bad ? __builtin_nanf("") : 1.0f);
           __syncthreads();  // (s_bad is rewritten by the next follower's poll)
         }
       }
@@ -2081,13 +2078,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_group_kernel(const TnJob*
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] += v[j];
           }
-          if (bad) {  // a partial never arrived: poison the tile (the finite-loss check of the engine stops the run)
-            const float nanv = __builtin_nanf("");
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-              for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{nanv, nanv, nanv, nanv};
-          }
+          acc[0][0] = acc[0][0] * (bad ? __builtin_nanf("") : 1.0f);  // a partial never arrived: poison the tile (the finite-loss check of the engine stops the run)
           __syncthreads();  // s_bad is rewritten by the next follower's poll
         }
       }
