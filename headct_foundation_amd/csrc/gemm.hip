@@ -1080,6 +1080,28 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
 #ifdef HCT_PRIO_YOUNG
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
+  // +residual epilogue: the tile's fp32 residual rows (256 KiB) are read in the epilogue, with the matrix pipes idle.  HCT_RES_TOUCH:
+  // one dword of each of their 128-B lines is requested ~12 K-steps before the main loop ends (4 loads per wave into a sink
+  // register), so that the epilogue's loads find the lines on the chip (L2 / Infinity Cache) instead of paying the HBM round trip
+  // in a burst with every other CU's.
+#ifndef HCT_RES_TOUCH
+#define HCT_RES_TOUCH 0
+#endif
+  uint32_t res_sink = 0;
+  auto res_touch = [&]() {
+    if (!(HCT_RES_TOUCH && MODE == EPI_RES_F32)) return;
+    int ldr = (int)e.ldr;
+    asm volatile("" : "+s"(ldr));
+    const char* rp = (const char*)e.residual + ((int64_t)m0 * ldr + n0) * 4;
+    const i32x4 rres = make_srd(rp, clamp_records((((int64_t)(M - m0 - 1) * ldr + (N - n0))) * 4));
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t off = (uint32_t)(((wave * 32 + j * 8 + (ln >> 3)) * ldr) * 4 + (ln & 7) * 128);
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(res_sink) : "v"(off), "s"(rres) : "memory");
+    }
+  };
   if (SK && it_first) take_item(it_first);
   else if (!next_item()) return;  // (only with stream-K: more workgroups than K ranges and no whole tiles)
   stage_pair(0);
@@ -1129,6 +1151,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
       rd_b(t + 1, 1, b_hi);
       mma(0, a1, b_lo);
       land_first(t);
+      if (HCT_RES_TOUCH && MODE == EPI_RES_F32 && (t + 16 == cns || (cns < 16 && t == 0))) res_touch();
 #if HCT_STAGGER_DMA
       if (wave < 4) stage_pair(t + 4);
       __builtin_amdgcn_sched_barrier(0);
@@ -1171,6 +1194,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     mma(0, a1, b_lo);
     mma(1, a1, b_hi);
 
+    if (HCT_RES_TOUCH && MODE == EPI_RES_F32) asm volatile("" ::"v"(res_sink));  // (the touch loads write it: allocated until here)
     __builtin_amdgcn_s_barrier();  // every wave has its last fragments in registers: the whole ring is free
     HCT_STAMP(2);
     if (MODE != EPI_GENERIC) {
