@@ -18,7 +18,7 @@
 
 namespace hct {
 
-int g_attn_bwd3 = 54;  // bit5: the encoder's bwd3 instance is four waves x one key tile (44.7 us) instead of two x two (53.5 us).  bit4: bwd4 as 16 waves x one key tile (128 registers, four waves per SIMD: 287 vs 305 us, -0.09 ms per step) instead of 8 x two.  bit3 (opt-in: measured equal to the kernel it would replace, 116 vs 117 us): persistent forward (fwd4) for head dim 48 with 193 .. 224 tokens.  Which shapes use the key-owner five-product backward: bit0 head dim 48 (<= 256 tokens, bwd3), bit1 head dim 64 (<= 192 tokens, bwd3), bit2 head dim 48 with 193 .. 224 tokens (persistent bwd4)
+int g_attn_bwd3 = 54 + 128;  // bit8 (opt-in, slower): bwd5 for head dim 64 too.   // bit7: long sequences (225 .. 576 tokens) on the five-product one-wave-per-SIMD kernel (bwd5) instead of the two-phase one.   // bit5: the encoder's bwd3 instance is four waves x one key tile (44.7 us) instead of two x two (53.5 us).  bit4: bwd4 as 16 waves x one key tile (128 registers, four waves per SIMD: 287 vs 305 us, -0.09 ms per step) instead of 8 x two.  bit3 (opt-in: measured equal to the kernel it would replace, 116 vs 117 us): persistent forward (fwd4) for head dim 48 with 193 .. 224 tokens.  Which shapes use the key-owner five-product backward: bit0 head dim 48 (<= 256 tokens, bwd3), bit1 head dim 64 (<= 192 tokens, bwd3), bit2 head dim 48 with 193 .. 224 tokens (persistent bwd4)
 int g_attn_dbg = 0;  // timing experiments on the backward kernel: bit0 skip key-owner pass, bit1 skip query-owner pass
 
 namespace {
@@ -1270,6 +1270,238 @@ __global__ void __launch_bounds__(1024 / KT, 2 * 2 / KT) attn_bwd4_kernel(const 
 }
 
 // ============================================================================================================
+// Backward for LONG sequences (bwd5: 225 .. 576 tokens -- the ViT-L/128^3 decoder's 513 at head dim 48, DINO's 517 at head dim 64):
+// the five-product key-owner algorithm of bwd3 / bwd4 where the Q / dO / K images of a head no longer fit LDS together (the
+// two-phase kernel these lengths ran on pays seven products and two passes over the images).
+//   * ONE wave per SIMD (four waves, the whole 512-register file each): a wave owns KT = 9 consecutive 16-key tiles, their
+//     dK^T / dV^T accumulators (up to 288 registers) and V rows (72) stay in registers for the whole head; every streamed
+//     fragment of a query block is fetched once and shared by the nine tiles;
+//   * only the K image is resident in LDS (rows for S = Q.K^T, transposed reads for dQ^T = K^T.dS^T); Q and dO stream through a
+//     two-slot ring of 32-row blocks: the rows of block j+1 (and the matching O rows, for delta = rowsum(dO . O)) are requested
+//     into registers at the top of block j and written to the other slot behind its arithmetic -- plain loads the compiler
+//     counts, no LDS-DMA in the loop;
+//   * dS^T is double-buffered, so the dQ product of block j-1 runs in the same barrier interval as the main part of block j:
+//     one barrier per block;  no atomics, fixed summation order.
+// LDS at 544 padded tokens, head dim 64: K 68 KiB + ring 16 KiB + dS^T 2 x 34 KiB = 153 KiB.
+template <int DH, int KT>
+__global__ void __launch_bounds__(256, 1) attn_bwd5_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                           const bf16* __restrict__ d_o, const float* __restrict__ lse, int N, int H,
+                                                           int Npad, bf16* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ROW = HeadImg<DH>::kRow, CH = HeadImg<DH>::kChunks, ND = DH / 16;
+  constexpr int blk = 32 * ROW;                      // one 32-row block image
+  unsigned char* const Kimg = smem;                  // Npad rows, then 32 zero bytes (the last row's padded fragment reads them)
+  unsigned char* const ring = Kimg + Npad * ROW + 32;  // [2][Q block | dO block], then 32 zero bytes
+  unsigned char* const dsT0 = ring + 4 * blk + 32;   // [2][2 halves][Npad][32 B]
+  constexpr int kRows = 4 * KT * 16;                  // dS^T rows per query half: every tile slot of every wave has its own (no branch around the writes)
+  constexpr int dstsz = 2 * kRows * 32;
+  float* const sLse = reinterpret_cast<float*>(dsT0 + 2 * dstsz);  // [2][32]
+  float* const sDel = sLse + 64;                                   // [2][32]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bh = xcd_bh(), b = bh / H, h = bh - b * H;
+  const int64_t rs = (int64_t)3 * H * DH, os = (int64_t)H * DH;
+  const bf16* qb = qkv + (int64_t)b * N * rs + h * DH;
+  const bf16* kb = qb + H * DH;
+  const bf16* vb = qb + 2 * H * DH;
+  const bf16* ob = o + (int64_t)b * N * os + h * DH;
+  const bf16* dob = d_o + (int64_t)b * N * os + h * DH;
+  const float* lse_row = lse + (int64_t)bh * N;
+  const float scale = rsqrtf((float)DH);
+  const float scale2 = scale * 1.44269504088896340736f;
+  const int g = lane >> 4;
+  const int key_base = wave * (KT * 16);
+  const int nqb = Npad >> 5;
+
+  // every byte a padded fragment may read must be finite (0 x NaN = NaN on the matrix pipe): ring, its pad and K's pad
+  for (int i = threadIdx.x * 16; i < 4 * blk + 32; i += 256 * 16) *reinterpret_cast<f32x4*>(ring + i) = f32x4{0, 0, 0, 0};
+  if (threadIdx.x < 2) *reinterpret_cast<f32x4*>(Kimg + Npad * ROW + threadIdx.x * 16) = f32x4{0, 0, 0, 0};
+  dma_image<DH>(Kimg, kb, rs, N, Npad, wave, 4, lane);
+  RowFrag<DH> vf[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) vf[t] = rows_global<DH>(vb, rs, key_base + t * 16, lane, N);
+
+  // staging of one query block: thread -> (row tid >> 3, 16-byte chunk tid & 7) of Q, dO and O; thread < 32 -> the row's lse
+  const int srow = threadIdx.x >> 3, sc = threadIdx.x & 7;
+  bf16x8 sq, sd, so;
+  float sl = 0.f;
+  auto stage_load = [&](int j) {
+    const int r = j * 32 + srow;
+    sq = sd = so = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < N && sc < CH) {
+      sq = *reinterpret_cast<const bf16x8*>(qb + (int64_t)r * rs + sc * 8);
+      sd = *reinterpret_cast<const bf16x8*>(dob + (int64_t)r * os + sc * 8);
+      so = *reinterpret_cast<const bf16x8*>(ob + (int64_t)r * os + sc * 8);
+    }
+    const int rl = j * 32 + (int)threadIdx.x;
+    sl = (threadIdx.x < 32 && rl < N) ? lse_row[rl] : 0.f;
+  };
+  auto stage_write = [&](int j) {
+    unsigned char* Qb = ring + (j & 1) * 2 * blk;
+    if (sc < CH) {
+      *reinterpret_cast<bf16x8*>(Qb + HeadImg<DH>::off(srow, sc)) = sq;
+      *reinterpret_cast<bf16x8*>(Qb + blk + HeadImg<DH>::off(srow, sc)) = sd;
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part += (float)so[e] * (float)sd[e];
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    // delta times the softmax scale: dS = P (dP scale - delta scale); lse in base 2, +inf on padded query rows (p = 0)
+    if (sc == 0) sDel[(j & 1) * 32 + srow] = j * 32 + srow < N ? part * scale : 0.f;
+    if (threadIdx.x < 32) sLse[(j & 1) * 32 + threadIdx.x] = j * 32 + (int)threadIdx.x < N ? sl * 1.44269504088896340736f : INFINITY;
+  };
+  stage_load(0);
+  stage_write(0);
+
+  f32x4 dKt[KT][ND], dVt[KT][ND];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) dKt[t][dt] = dVt[t][dt] = f32x4{0, 0, 0, 0};
+  __syncthreads();  // K image landed (hipcc drains the LDS-DMA in front of the barrier), block 0 staged
+
+  auto main_part = [&](int j) {
+    const unsigned char* Qb = ring + (j & 1) * 2 * blk;
+    const unsigned char* Db = Qb + blk;
+    unsigned char* dsT = dsT0 + (j & 1) * dstsz;
+    RowFrag<DH> qr[2], dr[2];
+    f32x4 L4[2], D4[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      qr[hh] = rows_lds<DH>(Qb, 16 * hh, lane, true);
+      dr[hh] = rows_lds<DH>(Db, 16 * hh, lane, false);  // (its partner, the V fragment, is the zero-padded side)
+      L4[hh] = *reinterpret_cast<const f32x4*>(sLse + (j & 1) * 32 + 16 * hh + 4 * g);
+      D4[hh] = *reinterpret_cast<const f32x4*>(sDel + (j & 1) * 32 + 16 * hh + 4 * g);
+    }
+    bf16x8 qT[ND], dT[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+      qT[dt] = cols_lds<DH>(Qb, 0, 16, dt * 16, lane);
+      dT[dt] = cols_lds<DH>(Db, 0, 16, dt * 16, lane);
+    }
+    // One wave per SIMD has nobody to cover its latencies, so the tile loop is software-pipelined by hand: the S / dP products of
+    // tile t+1 are ISSUED before the exponentials of tile t (they run on the matrix pipe under that arithmetic), the K rows of
+    // tile t+2 are requested before them, and the dV / dK products of tile t go out behind its arithmetic, under tile t+1's.
+    // (tiles at or past Npad -- the last wave's spare ones -- run on K row 0 and zero V rows: finite, never stored)
+    auto krows = [&](int t) { const int key0 = key_base + t * 16; return rows_lds<DH>(Kimg, key0 < Npad ? key0 : 0, lane, false); };
+    RowFrag<DH> kfA = krows(0), kfB = krows(KT > 1 ? 1 : 0);
+    f32x4 sc[2], pc[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      sc[hh] = mma_rows<DH>(qr[hh], kfA, f32x4{0, 0, 0, 0});    // S[q = 4g+r][key = lane&15]
+      pc[hh] = mma_rows<DH>(dr[hh], vf[0], f32x4{0, 0, 0, 0});  // dP[q][key]
+    }
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int key = key_base + t * 16 + (lane & 15);
+      f32x4 sn[2] = {sc[0], sc[1]}, pn[2] = {pc[0], pc[1]};
+      kfA = kfB;
+      if (t + 2 < KT) kfB = krows(t + 2);
+      if (t + 1 < KT) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          sn[hh] = mma_rows<DH>(qr[hh], kfA, f32x4{0, 0, 0, 0});
+          pn[hh] = mma_rows<DH>(dr[hh], vf[t + 1], f32x4{0, 0, 0, 0});
+        }
+      }
+      // No key mask: a probability is clamped to [0, 1] (free: an output modifier of v_exp_f32), so the keys past the last token --
+      // zero K and V rows, S = dP = 0 -- give finite P and dS whatever lse is; their dK / dV rows are never stored and their dS
+      // meets zero K rows in the dQ product.
+      f32x4 P[2], dS[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          P[hh][r] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(fmaf(sc[hh][r], scale2, -L4[hh][r])), 0.f, 1.f);
+          dS[hh][r] = P[hh][r] * fmaf(pc[hh][r], scale, -D4[hh][r]);
+        }
+      }
+      const bf16x8 pa = pack8(P[0], P[1]);
+      const bf16x8 dsa = pack8(dS[0], dS[1]);
+      const bf16x4 d0 = {dsa[0], dsa[1], dsa[2], dsa[3]}, d1 = {dsa[4], dsa[5], dsa[6], dsa[7]};
+      *reinterpret_cast<bf16x4*>(dsT + dst_off(kRows, 0, key, g)) = d0;
+      *reinterpret_cast<bf16x4*>(dsT + dst_off(kRows, 1, key, g)) = d1;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        dVt[t][dt] = MFMA(dT[dt], pa, dVt[t][dt]);   // dV^T[d][key] += dO^T.P
+        dKt[t][dt] = MFMA(qT[dt], dsa, dKt[t][dt]);  // dK^T[d][key] += Q^T.dS
+      }
+      sc[0] = sn[0]; sc[1] = sn[1]; pc[0] = pn[0]; pc[1] = pn[1];
+    }
+  };
+  // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] of block j: d-tile = wave, both query halves share the K^T fragment
+  auto dq_part = [&](int j) {
+    const unsigned char* dsT = dsT0 + (j & 1) * dstsz;
+    for (int dt = wave; dt < ND; dt += 4) {
+      f32x4 dq0 = {0, 0, 0, 0}, dq1 = {0, 0, 0, 0};
+      const int qq = (lane & 15) >> 2, pp = lane & 3;
+      auto ds_frag = [&](int hh, int k0) -> bf16x8 {
+        const int ka = k0 + 4 * g + qq;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dsT + dst_off(kRows, hh, ka, pp)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dsT + dst_off(kRows, hh, ka + 16, pp)));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+      };
+      // four key steps of fragments in flight ahead of their MFMAs (the registers are there)
+      constexpr int D = 4;
+      bf16x8 kT[D], b0[D], b1[D];
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        const int k0 = u * 32 < Npad ? u * 32 : 0;
+        kT[u] = cols_lds<DH>(Kimg, k0, k0 + 16, dt * 16, lane);
+        b0[u] = ds_frag(0, k0);
+        b1[u] = ds_frag(1, k0);
+      }
+      for (int k0 = 0; k0 < Npad; k0 += 32 * D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+          if (k0 + u * 32 < Npad) {  // wave-uniform
+            dq0 = MFMA(kT[u], b0[u], dq0);
+            dq1 = MFMA(kT[u], b1[u], dq1);
+          }
+          const int kn = k0 + (u + D) * 32;
+          if (kn < Npad) {
+            kT[u] = cols_lds<DH>(Kimg, kn, kn + 16, dt * 16, lane);
+            b0[u] = ds_frag(0, kn);
+            b1[u] = ds_frag(1, kn);
+          }
+        }
+      }
+      const int q = j * 32 + (lane & 15);
+      if (q < N) Vec4<bf16>::store(dqkv + ((int64_t)b * N + q) * rs + h * DH + dt * 16 + 4 * g, dq0);
+      if (q + 16 < N) Vec4<bf16>::store(dqkv + ((int64_t)b * N + q + 16) * rs + h * DH + dt * 16 + 4 * g, dq1);
+    }
+  };
+
+  for (int j = 0; j < nqb; ++j) {
+    if (j + 1 < nqb) stage_load(j + 1);  // in flight under this block's arithmetic
+    main_part(j);
+    if (j > 0) dq_part(j - 1);
+    if (j + 1 < nqb) stage_write(j + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  dq_part(nqb - 1);
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    const int key = key_base + t * 16 + (lane & 15);
+    if (key < N) {
+      bf16* outk = dqkv + ((int64_t)b * N + key) * rs + H * DH + h * DH + 4 * g;
+      bf16* outv = outk + H * DH;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        Vec4<bf16>::store(outk + dt * 16, dKt[t][dt]);
+        Vec4<bf16>::store(outv + dt * 16, dVt[t][dt]);
+      }
+    }
+  }
+}
+template <int DH>
+inline size_t bwd5_lds(int Npad, int KT) { return (size_t)Npad * HeadImg<DH>::kRow + 32 + (size_t)4 * 32 * HeadImg<DH>::kRow + 32 + (size_t)2 * 2 * (4 * KT * 16) * 32 + 512; }
+
+// ============================================================================================================
 // Forward, PERSISTENT form (fwd4) for the decoder shape (head dim 48, 193 .. 224 tokens): the structure of bwd4 without any
 // exchange between waves.  One 16-wave workgroup per CU walks the (batch, head) items; the next item's Q / K / V images land by
 // LDS-DMA in the other LDS buffer while the current one is computed; one barrier per item.  A wave owns one 16-query tile, keeps
@@ -1506,6 +1738,20 @@ int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const fl
     // and 83.6 for twelve waves x one key tile), so bwd3 takes them only when forced onto every shape it covers (bits 0 and 1)
     if (dh == 64 && Npad <= 192 && (g_attn_bwd3 & 3) == 3) HCT_BWD3(64, 4, 3, 2);
 #undef HCT_BWD3
+  }
+  if (!(g_attn_dbg & (4 | 8 | 32)) && (g_attn_bwd3 & 128) && Npad > 224 && Npad <= 576) {
+    // long sequences (ViT-L decoder: 513 tokens at head dim 48; DINO: 517 at 64): five-product key-owner kernel, one wave per SIMD
+#define HCT_BWD5(DH_, KT_)                                                                                                       \
+  do {                                                                                                                           \
+    const size_t l5 = bwd5_lds<DH_>(Npad, KT_);                                                                                      \
+    if (int rc = set_lds(attn_bwd5_kernel<DH_, KT_>, l5)) return rc;                                                             \
+    hipLaunchKernelGGL((attn_bwd5_kernel<DH_, KT_>), dim3(B * H), dim3(256), l5, s, (const bf16*)qkv, (const bf16*)o,            \
+                       (const bf16*)d_o, lse, N, H, Npad, (bf16*)dqkv);                                                          \
+    return check_hip(hipGetLastError(), "attention_bwd5");                                                                       \
+  } while (0)
+    if (dh == 48) HCT_BWD5(48, 9);
+    if (dh == 64 && (g_attn_bwd3 & 256)) HCT_BWD5(64, 9);  // (opt-in: 288 accumulator registers + 72 of V rows spill, 914 us against the two-phase kernel's 605 on DINO's 517 tokens)
+#undef HCT_BWD5
   }
   if (!(g_attn_dbg & 4) || bwd_lds(N) > (size_t)kMaxLds) {  // single-phase variant (testing hook) only where its 4 images fit
     const size_t l2 = bwd2_lds(N);

@@ -495,6 +495,12 @@ constexpr int kNT = HCT_EPI_CACHE_POLICY;
 #ifndef HCT_RES_POLICY
 #define HCT_RES_POLICY 16  /* the fp32 residual-stream output, read back by the next LayerNorm: sc1 39.76 / write-back 39.77 / nt 39.84 ms per step; with LayerNorm's non-temporal loads: sc1 39.28 / write-back 39.33 / nt 39.45 */
 #endif
+#ifndef HCT_EPI_LA_WIDE  /* look-ahead (sub-tiles of 16 rows x 64 columns) of the half-width epilogue's loads: bf16 aux (x gelu') / fp32 residual */
+#define HCT_EPI_LA_WIDE 1
+#endif
+#ifndef HCT_EPI_LA_F32
+#define HCT_EPI_LA_F32 1
+#endif
 #ifndef HCT_SLAB_POLICY
 #define HCT_SLAB_POLICY 16  /* cache policy of the wgrad's split-K slab stores: 16 = sc1 write-through (39.83 ms per step), 0 = write-back (39.90), 2 = nt (40.17) */
 #endif
@@ -711,7 +717,13 @@ __device__ __forceinline__ void epilogue_wave64x128_h(const Epilogue& e, const T
   const int rows_left = M - m0 - row0;
   const uint32_t lane_c = (uint32_t)(rr * ldc + col), lane_r = (uint32_t)(rr * ldr + col), lane_x = (uint32_t)(rr * ldx + col);
 
-  u32x4 ld[2][T::loads ? NB : 1];
+  // Look-ahead of the residual / saved-gelu' loads in sub-tiles: with ONE sub-tile ahead a wave keeps 2 (bf16) or 4 (fp32) KiB in
+  // flight, 16 - 32 KiB per CU -- at an HBM round trip of 1 - 2 us under load that is 10 - 30 GB/s per CU, which is what these
+  // epilogues ran at (in-kernel stamps: 8.6 us for the x gelu' tile with 44 or with 256 workgroups active alike).  The accumulator
+  // registers free up as the sub-tiles leave (16 per sub-tile) and the main loop's 64 fragment registers are dead here.
+  constexpr int LA = T::wide ? HCT_EPI_LA_WIDE : HCT_EPI_LA_F32;
+  static_assert(LA >= 1 && LA <= 8, "look-ahead in sub-tiles");
+  u32x4 ld[T::loads ? 8 : 1][T::loads ? NB : 1];
   auto issue_loads = [&](int s) {  // sub-tile s = 2 i + h
     if (!T::loads) return;
     const int i = s >> 1, h = s & 1;
@@ -720,18 +732,19 @@ __device__ __forceinline__ void epilogue_wave64x128_h(const Epilogue& e, const T
     for (int it = 0; it < NB; ++it) {
       const int prow = i * 16 + it * RB;
       const bool ok = nok && prow + rr < rows_left;
-      if (MODE == EPI_RES_F32) ld[s & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(tb.res, ok ? (lane_r + h * 64) * 4u : OOB, (row0 + prow) * ldr * 4, kNT);
-      else ld[s & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(tb.aux, ok ? (lane_x + h * 64) * 2u : OOB, (row0 + prow) * ldx * 2, kNT);
+      if (MODE == EPI_RES_F32) ld[s][it] = __builtin_amdgcn_raw_buffer_load_b128(tb.res, ok ? (lane_r + h * 64) * 4u : OOB, (row0 + prow) * ldr * 4, kNT);
+      else ld[s][it] = __builtin_amdgcn_raw_buffer_load_b128(tb.aux, ok ? (lane_x + h * 64) * 2u : OOB, (row0 + prow) * ldx * 2, kNT);
     }
   };
-  issue_loads(0);
+#pragma unroll
+  for (int s = 0; s < LA; ++s) issue_loads(s);
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     const int i = s >> 1, h = s & 1;
     const bool nok = n0 + col + h * 64 < N;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4*>(patch + frow * 256 + (((jj * 4 + fchk) ^ frow) << 4)) = acc[i][h * 4 + jj];
-    if (s < 7) issue_loads(s + 1);  // one sub-tile ahead and BEFORE this sub-tile's stores: waiting for it never drains them
+    if (s + LA < 8) issue_loads(s + LA);  // LA sub-tiles ahead and BEFORE this sub-tile's stores: waiting for it never drains them
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
       const int pr = it * RB + rr;        // row inside the 16-row patch
@@ -769,7 +782,7 @@ __device__ __forceinline__ void epilogue_wave64x128_h(const Epilogue& e, const T
             }
           }
         } else if (MODE == EPI_DGELU_BF16 || MODE == EPI_DGELU_CS) {
-          const bf16x8 t = __builtin_bit_cast(bf16x8, ld[s & 1][it]);
+          const bf16x8 t = __builtin_bit_cast(bf16x8, ld[s][it]);
           if (e.aux_deriv) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -793,7 +806,7 @@ __device__ __forceinline__ void epilogue_wave64x128_h(const Epilogue& e, const T
       } else {
         const f32x4 v = *reinterpret_cast<const f32x4*>(patch + pr * 256 + ((cc ^ pr) << 4));
         f32x4 x = v * e.alpha + bias[h].lo;
-        if (MODE == EPI_RES_F32) x += __builtin_bit_cast(f32x4, ld[s & 1][it]);
+        if (MODE == EPI_RES_F32) x += __builtin_bit_cast(f32x4, ld[s][it]);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), tb.c, ok ? (lane_c + h * 64) * 4u : OOB, (row0 + prow) * ldc * 4, STORE_POLICY);
         HCT_STORE_GUARD();
       }
@@ -1080,25 +1093,34 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
 #ifdef HCT_PRIO_YOUNG
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
-  // +residual epilogue: the tile's fp32 residual rows (256 KiB) are read in the epilogue, with the matrix pipes idle.  HCT_RES_TOUCH:
-  // one dword of each of their 128-B lines is requested ~12 K-steps before the main loop ends (4 loads per wave into a sink
-  // register), so that the epilogue's loads find the lines on the chip (L2 / Infinity Cache) instead of paying the HBM round trip
-  // in a burst with every other CU's.
-#ifndef HCT_RES_TOUCH
-#define HCT_RES_TOUCH 0
+  // Epilogues that LOAD (fp32 residual: 256 KiB per tile; saved gelu': 128 KiB) are bound by the CU's miss path: a CU draws ~30 GB/s
+  // from beyond its L2 however many loads it keeps in flight (in-kernel stamps: the x gelu' epilogue takes 8.2 us with one sub-tile
+  // of look-ahead and 7.6 + 1 with the whole tile requested up front, HCT_EPI_LA_*; the plain one 3.1), with the matrix pipes idle.
+  // HCT_EPI_TOUCH (bit m: epilogue mode m; experiment): one dword of each 128-B line of the tile's residual / aux rows is requested
+  // right behind the item's LAST stage pair -- 6 K-steps before the main loop ends; nothing younger is ever waited for inside the
+  // loop, the one remaining landing wait is counted -- so that the epilogue's loads find the lines in L2.  (Round 3's first form
+  // issued them 12 K-steps early: the in-order vmcnt wait of the NEXT pair then stalled the loop for an HBM round trip.)
+#ifndef HCT_EPI_TOUCH
+#define HCT_EPI_TOUCH 0
 #endif
+  constexpr bool kTouch = ((HCT_EPI_TOUCH >> MODE) & 1) && EpiTraits<MODE>::loads;
+  constexpr int kTouchOps = MODE == EPI_RES_F32 ? 4 : 2;  // per wave: 2048 / 1024 lines per tile
   uint32_t res_sink = 0;
   auto res_touch = [&]() {
-    if (!(HCT_RES_TOUCH && MODE == EPI_RES_F32)) return;
-    int ldr = (int)e.ldr;
-    asm volatile("" : "+s"(ldr));
-    const char* rp = (const char*)e.residual + ((int64_t)m0 * ldr + n0) * 4;
-    const i32x4 rres = make_srd(rp, clamp_records((((int64_t)(M - m0 - 1) * ldr + (N - n0))) * 4));
+    if (!kTouch) return;
+    const bool f32 = MODE == EPI_RES_F32;
+    int ldt = f32 ? (int)e.ldr : (int)e.ldaux;
+    asm volatile("" : "+s"(ldt));
+    const int esz = f32 ? 4 : 2;
+    const char* rp = (f32 ? (const char*)e.residual : (const char*)e.aux) + ((int64_t)m0 * ldt + n0) * esz;
+    const i32x4 rres = make_srd(rp, clamp_records((((int64_t)(M - m0 - 1) * ldt + (N - n0))) * esz));
     int ln = lane;
     asm volatile("" : "+v"(ln));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t off = (uint32_t)(((wave * 32 + j * 8 + (ln >> 3)) * ldr) * 4 + (ln & 7) * 128);
+    for (int j = 0; j < kTouchOps; ++j) {
+      // fp32: 8 lines per row, 8 rows per load; bf16: 4 lines per row, 16 rows per load
+      const int row = f32 ? wave * 32 + j * 8 + (ln >> 3) : wave * 32 + j * 16 + (ln >> 2);
+      const uint32_t off = (uint32_t)(row * ldt * esz + (f32 ? (ln & 7) : (ln & 3)) * 128);
       asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(res_sink) : "v"(off), "s"(rres) : "memory");
     }
   };
@@ -1138,6 +1160,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     // previous odd step).  Odd step t+1: pair (t+2, t+3), issued two steps ago, must have landed; every wave is then past
     // its reads of stages t-1 and t, whose buffers take pair (t+4, t+5).
     int t = 0;
+    bool touched = false;
     // The two waves of a SIMD (w and w + 4) run the same program between the same barriers: both issue their 8 DMA pieces
     // right behind the barrier (an LDS-DMA piece holds the issuing wave for 60 - 185 cycles, MI355X_MICROARCH.md) and then both
     // want the matrix pipe.  HCT_STAGGER_DMA: waves 4 - 7 issue theirs one MFMA group later, so that on every SIMD one wave issues
@@ -1151,13 +1174,16 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
       rd_b(t + 1, 1, b_hi);
       mma(0, a1, b_lo);
       land_first(t);
-      if (HCT_RES_TOUCH && MODE == EPI_RES_F32 && (t + 16 == cns || (cns < 16 && t == 0))) res_touch();
 #if HCT_STAGGER_DMA
       if (wave < 4) stage_pair(t + 4);
       __builtin_amdgcn_sched_barrier(0);
 #else
       stage_pair(t + 4);
 #endif
+      if (kTouch && t + 6 == cns && !(SK && ((item >> 8) & 1023))) {  // the item's last pair is out: nothing younger is waited for in the loop
+        res_touch();
+        touched = true;
+      }
       rd_a(t + 2, a0);
       rd_b(t + 2, 0, b_lo);
       mma(1, a1, b_hi);
@@ -1174,7 +1200,12 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     mma(1, a0, b_hi);
     rd_b(t + 1, 1, b_hi);
     mma(0, a1, b_lo);
-    land_first(t);  // pair (cns-2, cns-1)
+    if (kTouch && touched) {  // pair (cns-2, cns-1) is older than the touches: a counted wait
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kTouchOps) : "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      land_first(t);  // pair (cns-2, cns-1)
+    }
     rd_a(t + 2, a0);
     rd_b(t + 2, 0, b_lo);
     mma(1, a1, b_hi);
@@ -1194,7 +1225,10 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     mma(0, a1, b_lo);
     mma(1, a1, b_hi);
 
-    if (HCT_RES_TOUCH && MODE == EPI_RES_F32) asm volatile("" ::"v"(res_sink));  // (the touch loads write it: allocated until here)
+    if (kTouch) {  // the touch loads write res_sink whenever they return: it stays allocated until they have
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("" ::"v"(res_sink));
+    }
     __builtin_amdgcn_s_barrier();  // every wave has its last fragments in registers: the whole ring is free
     HCT_STAMP(2);
     if (MODE != EPI_GENERIC) {

@@ -19,7 +19,7 @@ stamps = torch.zeros(256 * 64, dtype=torch.int32, device=dev)
 _lib.check(lib.hct_debug_set_stamp_buffer(stamps.data_ptr(), stamps.numel()), "stamp buffer")
 
 
-def call(name, M, N, K, out_f32=False, bias=False, residual=False, act=0, stagger=-1):
+def call(name, M, N, K, out_f32=False, bias=False, residual=False, act=0, stagger=-1, colsum=False):
     a = GemmArgs()
     A = torch.randn(M, K, device=dev).bfloat16(); B = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
     a.A, a.a_dtype, a.lda, a.transA = A.data_ptr(), HCT_BF16, K, 0
@@ -35,6 +35,8 @@ def call(name, M, N, K, out_f32=False, bias=False, residual=False, act=0, stagge
     if act:
         aux = torch.randn(M, N, device=dev).bfloat16(); a.aux, a.aux_dtype, a.ldaux = aux.data_ptr(), HCT_BF16, N; keep.append(aux)
     a.act = act; a.alpha = 1.0
+    if colsum:
+        cso = torch.zeros(N, device=dev); a.colsum_out = cso.data_ptr(); keep.append(cso)
     ws = torch.empty(max(16, lib.hct_gemm_workspace_bytes(C.byref(a))), dtype=torch.uint8, device=dev)
     lib.hct_debug_set_gemm_variant(256)
     lib.hct_debug_set_gemm_stagger(stagger)
@@ -72,6 +74,11 @@ for stg in ([int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()] or (-1, 0)
     if "qkv" in which: call("qkv fwd (plain bf16)", Md, 2304, 768, stagger=stg)
     if "fc1" in which: call("fc1 fwd (GELU, aux, bias)", Md, 3072, 768, bias=True, act=1, stagger=stg)
     if "dgelu" in which: call("fc2 dgrad (x gelu')", Md, 3072, 768, act=2, stagger=stg)
+    # the forms the training step uses: forward saves gelu' (act 4), the backward multiplies by it and sums columns (act 5)
+    if "fc1d" in which: call("fc1 fwd (GELU + saved gelu', bias)", Md, 3072, 768, bias=True, act=4, stagger=stg)
+    if "mulaux" in which: call("fc2 dgrad (x saved gelu' + column sums)", Md, 3072, 768, act=5, stagger=stg, colsum=True)
+    if "encmulaux" in which: call("encoder fc2 dgrad (x saved gelu' + column sums)", 256 * 55, 3072, 768, act=5, stagger=stg, colsum=True)
+    if "encproj" in which: call("encoder proj fwd (+bias +res f32)", 256 * 55, 768, 768, out_f32=True, bias=True, residual=True, stagger=stg)
     if "proj" in which: call("proj fwd (+bias +res f32)", Md, 768, 768, out_f32=True, bias=True, residual=True, stagger=stg)
     # 651 tiles: with the stream-K remainder round (default; HCT_NT_STREAMK_PAIRS=1000000 switches it off) item 0 / 1 of a
     # workgroup are its follower / owner pieces, whose "epilogue issue" column is the slab hand-over / the fix-up + epilogue
