@@ -633,6 +633,23 @@ __global__ void __launch_bounds__(NW * 64, (NW >= 8 ? HCT_BWD2_WPE : 2)) attn_bw
 }
 
 
+// Key-owner backward kernels (bwd3 / bwd4 / bwd5), keys past the last token: their K and V rows are ZERO in the images (range-checked
+// fill), so S = dP = 0 there; their dK / dV rows are never stored, and their dS only ever meets those zero K rows in the dQ product.
+// All that is needed of them is FINITE P and dS -- exp2(0 - lse) overflows when every real score of a row is very negative -- and a
+// probability clamped to [0, 1] is that: the clamp is an output modifier of v_exp_f32 (hipcc folds the med3), so the per-element
+// multiply + select of the explicit key mask (two of the ~7 VALU operations per score in these VALU-issue-bound loops) goes away.
+// A real probability is <= 1 up to rounding, so the clamp changes nothing else.  HCT_ATTN_CLAMP_MASK=0 restores the explicit mask (A/B).
+#ifndef HCT_ATTN_CLAMP_MASK
+#define HCT_ATTN_CLAMP_MASK 1
+#endif
+__device__ __forceinline__ float hct_prob(float p) {
+#if HCT_ATTN_CLAMP_MASK
+  return __builtin_amdgcn_fmed3f(p, 0.f, 1.f);
+#else
+  return p;
+#endif
+}
+
 // ============================================================================================================
 // Backward, key-owner form with FIVE products (bwd3): every wave owns KT consecutive 16-key tiles of one (batch, head)
 // and keeps their dK^T / dV^T in accumulators while the workgroup sweeps the queries in blocks of 32.
@@ -845,12 +862,14 @@ __global__ void __launch_bounds__(GS * 64, WPS) attn_bwd3_kernel(const bf16* __r
             const f32x4 dp = mma_rows<DH>(dr[hh], vf[t], Dinit);   // dP'[q][key]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              P[hh][r] = __builtin_amdgcn_exp2f(sacc[r] * scale2);
+              P[hh][r] = hct_prob(__builtin_amdgcn_exp2f(sacc[r] * scale2));
               dS[hh][r] = P[hh][r] * dp[r];
             }
           }
+#if !HCT_ATTN_CLAMP_MASK
           const float keep = key < N ? 1.f : 0.f;  // keys past the last token contribute nothing
           P[0] *= keep; P[1] *= keep; dS[0] *= keep; dS[1] *= keep;
+#endif
           const bf16x8 pa = pack8(P[0], P[1]);
           const bf16x8 dsa = pack8(dS[0], dS[1]);
           const bf16x4 d0 = {dsa[0], dsa[1], dsa[2], dsa[3]}, d1 = {dsa[4], dsa[5], dsa[6], dsa[7]};
@@ -1136,8 +1155,10 @@ __global__ void __launch_bounds__(1024 / KT, 2 * 2 / KT) attn_bwd4_kernel(const 
         // KT == 1: the wave's K fragment is fetched (and zero-padded) once per item, so the Q / dO fragments stream unpadded
         const RowFrag<DH> kf = KT == 1 ? kfh : rows_lds<DH>(Kimg, key0, ln, false);
         const int key = key0 + (ln & 15);
+#if !HCT_ATTN_CLAMP_MASK
         const float keep = key < N ? 1.f : 0.f;
         const bool tail_tile = key0 + 16 > N;  // wave-uniform: only the tile that straddles N masks its probabilities
+#endif
         f32x4 P[2], dS[2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -1151,8 +1172,10 @@ __global__ void __launch_bounds__(1024 / KT, 2 * 2 / KT) attn_bwd4_kernel(const 
           const f32x4 dp = mma_rows<DH>(dr[hh], vf[t], f32x4{0, 0, 0, 0});   // dP[q][key]
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            P[hh][r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale2, -L4[hh][r]));
+            P[hh][r] = hct_prob(__builtin_amdgcn_exp2f(fmaf(sacc[r], scale2, -L4[hh][r])));
+#if !HCT_ATTN_CLAMP_MASK
             if (tail_tile) P[hh][r] *= keep;
+#endif
             dS[hh][r] = P[hh][r] * fmaf(dp[r], scale, -D4[hh][r]);
           }
         }
