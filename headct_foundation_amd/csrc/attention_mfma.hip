@@ -1762,7 +1762,9 @@ int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const fl
     if (dh == 64 && Npad <= 192 && (g_attn_bwd3 & 3) == 3) HCT_BWD3(64, 4, 3, 2);
 #undef HCT_BWD3
   }
-  if (!(g_attn_dbg & (4 | 8 | 32)) && (g_attn_bwd3 & 128) && Npad > 224 && Npad <= 576) {
+  // (every wave runs its nine tile slots whatever the length: below ~450 tokens the spare slots make it slower than the two-phase
+  //  kernel -- 276 vs 239 us at 289 tokens, 363 vs 356 at 385, 507 vs 580 at 513, 502 vs 600 at 576; bit 9 forces it from 225 tokens on)
+  if (!(g_attn_dbg & (4 | 8 | 32)) && (g_attn_bwd3 & 128) && Npad > ((g_attn_bwd3 & 512) ? 224 : 448) && Npad <= 576) {
     // long sequences (ViT-L decoder: 513 tokens at head dim 48; DINO: 517 at 64): five-product key-owner kernel, one wave per SIMD
 #define HCT_BWD5(DH_, KT_)                                                                                                       \
   do {                                                                                                                           \
@@ -1773,7 +1775,7 @@ int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const fl
     return check_hip(hipGetLastError(), "attention_bwd5");                                                                       \
   } while (0)
     if (dh == 48) HCT_BWD5(48, 9);
-    if (dh == 64 && (g_attn_bwd3 & 256)) HCT_BWD5(64, 9);  // (opt-in: 288 accumulator registers + 72 of V rows spill, 914 us against the two-phase kernel's 605 on DINO's 517 tokens)
+    if (dh == 64 && (g_attn_bwd3 & 256)) HCT_BWD5(64, 9);  // (opt-in: 288 accumulator registers + 72 of V rows spill -- also with the block's column fragments re-read per tile --, 914 us against the two-phase kernel's 605 on DINO's 517 tokens)
 #undef HCT_BWD5
   }
   if (!(g_attn_dbg & 4) || bwd_lds(N) > (size_t)kMaxLds) {  // single-phase variant (testing hook) only where its 4 images fit

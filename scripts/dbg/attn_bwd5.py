@@ -6,7 +6,7 @@ from headct_foundation_amd import _lib
 if os.environ.get('HCT_LIB_TAG'):
     _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"libheadct_hip_{os.environ['HCT_LIB_TAG']}.so")
 lib = _lib.load(); dev = torch.device("cuda"); st = torch.cuda.current_stream().cuda_stream
-ON, OFF = 100000 + 54 + 128 + 256, 100000 + 54  # ON: bwd5 for both head dims (the default takes it for head dim 48 only)
+ON, OFF = 100000 + 54 + 128 + 256 + 512, 100000 + 54  # ON: bwd5 for both head dims (the default takes it for head dim 48 only)
 
 
 def ref(qkv, d_o, B, N, H, dh):

@@ -343,12 +343,12 @@ def test_attention_fwd_bwd(lib, cuda, B, N, H, dh, dtype):
     # 0 default (five-product key-owner backward where it applies), 1 fp32-math kernels, 2 online-softmax forward,
     # 14 single-phase backward, 42 two-phase seven-product backward
     # 100003: bwd3 key-owner backward on every shape it covers (the default uses it for head dim 64 only); 100000: two-phase
-    # everywhere; 100014: the opt-in persistent forward (fwd4) and the 8-wave form of bwd4; 100438: the long-sequence five-product
-    # kernel (bwd5, 225 .. 576 tokens) for head dim 64 too (default: head dim 48 only); the default (100182) takes the 16-wave
+    # everywhere; 100014: the opt-in persistent forward (fwd4) and the 8-wave form of bwd4; 100950: the long-sequence five-product
+    # kernel (bwd5) from 225 tokens on and for head dim 64 too (default: 449 .. 576 tokens at head dim 48); the default (100182) takes the 16-wave
     # persistent bwd4 for head dim 48
     # with 193 .. 224 tokens -- the last two cases
     # have more (batch, head) items than CUs, so its workgroups walk several items through both LDS buffers
-    for force_simple in ((0, 1, 2, 14, 42, 100003, 100000, 100014, 100438) if dtype == torch.bfloat16 else (0,)):
+    for force_simple in ((0, 1, 2, 14, 42, 100003, 100000, 100014, 100950) if dtype == torch.bfloat16 else (0,)):
         lib.hct_debug_force_simple_attention(force_simple)
         try:
             o = torch.empty(B, N, H * dh, dtype=dtype, device=cuda)
