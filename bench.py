@@ -292,9 +292,16 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # HCT_BENCH_RCCL1=1 (one-GPU box): world size ONE over the real "nccl" backend (= RCCL) with the data-parallel wrapper forced on, so
+    # that communicator set-up, the bucketed asynchronous all-reduce on RCCL's stream, the CU reserve and the final wait all execute
+    # on hardware (the sums are those of one rank); the step-time difference to the plain run bounds the compute-side cost of the wrapper
+    rccl1 = os.environ.get("HCT_BENCH_RCCL1") == "1" and world == 1 and args.config != "dino"
+    if world > 1 or rccl1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
+        if rccl1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", device_id=device, rank=0, world_size=1)
+        elif rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
@@ -310,7 +317,7 @@ def main():
     S = arch["input_size"]
     torch.manual_seed(42)  # reference init scheme at seed 42 (same weights on every rank; DDP broadcasts rank 0's anyway)
     model = MaskedAutoencoderViT(**arch, compute_dtype=args.dtype).to(device)
-    ddp = DistributedDataParallel(model, device_ids=[device], bucket_cap_mb=args.bucket_mb) if world > 1 else model
+    ddp = DistributedDataParallel(model, device_ids=[device], bucket_cap_mb=args.bucket_mb, force_collectives=rccl1) if (world > 1 or rccl1) else model
     total_steps = max(1000, args.steps + args.warmup)
     base_lr = 1.5e-4 * B * G / 256  # main_pretrain_mae.py:149-151
     opt = HipAdamW(ddp, lr=base_lr, weight_decay=5e-3, betas=(0.9, 0.95))
@@ -377,10 +384,13 @@ def main():
         }
         if prof and extra:
             out["other_kernels"] = extra
+        if rccl1:
+            out["config"]["parallelism"] = "dp1 over RCCL (HCT_BENCH_RCCL1: wrapper forced on at world size 1)"
+            out["rccl_buckets_per_step"] = [int(e - b) * 4 for b, e in ddp.launched]
         if world == 1 and not args.no_cpu_baseline and args.config == "vitb":  # the CPU sample is the headline workload
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or rccl1:
         dist.destroy_process_group()
 
 

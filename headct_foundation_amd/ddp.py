@@ -26,7 +26,8 @@ import torch.nn as nn
 
 class DistributedDataParallel(nn.Module):
     def __init__(self, module: nn.Module, device_ids=None, broadcast_buffers: bool = False,
-                 find_unused_parameters: bool = False, bucket_cap_mb: float = 64.0, process_group=None, grad_dtype: str = "fp32"):
+                 find_unused_parameters: bool = False, bucket_cap_mb: float = 64.0, process_group=None, grad_dtype: str = "fp32",
+                 force_collectives: bool = False):
         super().__init__()
         for attr in ("_flat", "_flat_grad", "_bucket_hook", "_post_backward_hook"):
             if not hasattr(module, attr):
@@ -34,6 +35,10 @@ class DistributedDataParallel(nn.Module):
         self.module = module
         self.process_group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force_collectives (rehearsal on a one-GPU box): with an initialised process group of ONE rank the wrapper still runs its whole
+        # data path -- grouped weight gradients every few stages, buckets, asynchronous all-reduce on the backend's stream, the CU
+        # reserve, the final wait -- so that the RCCL calls themselves execute on hardware; the sums are those of one rank.
+        self._active = self.world_size > 1 or (force_collectives and dist.is_initialized())
         self.bucket_bytes = int(bucket_cap_mb * (1 << 20))
         # "bf16": a bucket crosses the links as bfloat16 (298 MB per step instead of 595 MB for ViT-B) -- cast into a staging
         # buffer, SUM all-reduce, cast back into the fp32 gradient.  Each rank's gradient is rounded to 8 significant bits before
@@ -45,7 +50,7 @@ class DistributedDataParallel(nn.Module):
         self._open: Optional[Tuple[int, int]] = None  # [begin, end) of the bucket being filled
         self._works: List = []
         self.launched: List[Tuple[int, int]] = []      # ranges reduced during the last backward (for tests)
-        if self.world_size > 1:
+        if self._active:
             dist.broadcast(module._flat, src=0, group=process_group)  # DDP ctor: rank 0's parameters win
             if hasattr(module, "mark_weights_updated"):
                 module.mark_weights_updated()
@@ -56,13 +61,13 @@ class DistributedDataParallel(nn.Module):
         # the backward before the first bucket keep all CUs.
         self._reserve = 0
         self._set_reserve = None
-        if self.world_size > 1 and getattr(module, "_flat", None) is not None and module._flat.is_cuda:
+        if self._active and getattr(module, "_flat", None) is not None and module._flat.is_cuda:
             import os
             from . import _lib
             self._reserve = int(os.environ.get("HCT_CU_RESERVE", "16"))
             self._set_reserve = _lib.load().hct_set_cu_reserve
         module._grad_prescale = 1.0 / self.world_size
-        if self.world_size > 1 and getattr(module, "wgrad_group_blocks", 0) is None:
+        if self._active and getattr(module, "wgrad_group_blocks", 0) is None:
             import os
             module.wgrad_group_blocks = int(os.environ.get("HCT_WGRAD_GROUP_BLOCKS", "4"))
         module._bucket_hook = self._on_stage
@@ -70,7 +75,7 @@ class DistributedDataParallel(nn.Module):
 
     # called by the model after backward stage `stage` has been enqueued when a gradient range became final: [begin, end)
     def _on_stage(self, stage: int, begin: int, end: int) -> None:
-        if self.world_size == 1:
+        if not self._active:
             return
         if end == self.module._flat_grad.numel():  # first range of a backward
             self.launched = []
@@ -100,7 +105,7 @@ class DistributedDataParallel(nn.Module):
         self.launched.append((begin, end))
 
     def _finish(self) -> None:
-        if self.world_size == 1:
+        if not self._active:
             return
         if self._open is not None:
             self._launch(*self._open)

@@ -132,3 +132,22 @@ def test_bench_two_ranks_rehearsal(cuda):
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["config"]["global_batch"] == 16
     assert out["config"]["parallelism"] == "dp2" and out["value"] > 0 and abs(out["value"] - 16 * 1e3 / out["ms_per_step"]) < 0.01 * out["value"]
     assert "cpu_baseline" not in out and out["roofline"] is not None
+
+
+@pytest.mark.gpu
+def test_bench_rccl_world1(cuda):
+    """bench.py at world size ONE over the real "nccl" backend (= RCCL) with the data-parallel wrapper forced on (HCT_BENCH_RCCL1=1):
+    communicator set-up, the bucketed asynchronous all-reduce on RCCL's stream, the CU reserve and the final wait execute on
+    hardware (the driver's N > 1 runs are the only other place they do).  The sums are those of one rank, so the loss curve must be
+    the plain run's."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = {}
+    for tag, extra in (("plain", {}), ("rccl1", {"HCT_BENCH_RCCL1": "1", "MASTER_PORT": "29571"})):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "8", "--no-cpu-baseline"],
+                           capture_output=True, text=True, env=env, cwd=root, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert sum(lines["rccl1"]["rccl_buckets_per_step"]) > 0 and len(lines["rccl1"]["rccl_buckets_per_step"]) >= 2
+    assert abs(lines["rccl1"]["loss_last"] - lines["plain"]["loss_last"]) < 1e-4 * abs(lines["plain"]["loss_last"]) + 1e-6
