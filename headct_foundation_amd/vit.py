@@ -161,9 +161,9 @@ class ViT(nn.Module):
             # fp16 volumes (the persistent cache's storage type) are read as they are; anything else goes through fp32
             x = x.contiguous() if x.dtype == torch.float16 else x.to(torch.float32).contiguous()
             xdt = _lib.HCT_F16 if x.dtype == torch.float16 else _lib.HCT_F32
-            ids = torch.arange(L, dtype=torch.int32, device=dev).repeat(B, 1).contiguous()
             rows = torch.empty(B * L, self.in_chans * self.P ** 3, dtype=tdt, device=dev)
-            _lib.check(self._lib.hct_patch_gather(x.data_ptr(), xdt, ids.data_ptr(), B, self.in_chans, S, self.P, L, L, rows.data_ptr(), dt,
+            # (no index table: every patch in grid order -- the library then moves whole pencils of patches)
+            _lib.check(self._lib.hct_patch_gather(x.data_ptr(), xdt, None, B, self.in_chans, S, self.P, L, L, rows.data_ptr(), dt,
                                                   self._st), "hct_patch_gather")
             pe = self.patch_embedding
             tok = self._linear(rows, self._weight(pe.patch_embeddings.weight), pe.patch_embeddings.bias, tdt)

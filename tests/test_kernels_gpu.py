@@ -719,3 +719,25 @@ def test_hu_window_vs_oracle(lib, cuda, channels):
     got_h = window_hu(hu.half().to(cuda), channels, out_dtype=torch.float32)  # integer HU up to 2048 are exact in fp16
     assert torch.equal(got_h.cpu(), O.hu_window(hu.half().float(), channels))
     assert float(got32.min()) == 0.0 and float(got32.max()) == 1.0
+
+
+@pytest.mark.parametrize("B,C,S,P,xdt,rdt", [(2, 3, 96, 12, torch.float32, torch.bfloat16), (3, 1, 96, 16, torch.float16, torch.bfloat16),
+                                            (2, 3, 48, 12, torch.float32, torch.float32), (1, 2, 32, 8, torch.float16, torch.float32),
+                                            (1, 1, 128, 16, torch.float32, torch.bfloat16)])
+def test_patch_gather_all_patches(lib, cuda, B, C, S, P, xdt, rdt):
+    """hct_patch_gather without an index table (plain ViT / DINO crops: every patch in grid order) -- the pencil kernel where its LDS image
+    fits, the per-patch kernel otherwise -- against the Conv3d unfolding order (c, ph, pw, pd) of patch_embedding.py:149, and against the
+    same call WITH an identity table (the per-patch kernel): bit-equal."""
+    g = S // P
+    L = g ** 3
+    x = _rand((B, C, S, S, S), cuda, torch.float32, 77).to(xdt)
+    ref = x.float().view(B, C, g, P, g, P, g, P).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * L, C * P ** 3)
+    xd = _lib.HCT_F16 if xdt == torch.float16 else HCT_F32
+    rows = torch.full((B * L, C * P ** 3), float("nan"), dtype=rdt, device=cuda)
+    _lib.check(lib.hct_patch_gather(x.data_ptr(), xd, None, B, C, S, P, L, L, rows.data_ptr(), _dt(rows), _st()), "patch_gather")
+    ids = torch.arange(L, dtype=torch.int32, device=cuda).repeat(B, 1).contiguous()
+    rows2 = torch.full_like(rows, float("nan"))
+    _lib.check(lib.hct_patch_gather(x.data_ptr(), xd, ids.data_ptr(), B, C, S, P, L, L, rows2.data_ptr(), _dt(rows), _st()), "patch_gather")
+    torch.cuda.synchronize()
+    assert torch.equal(rows, rows2)
+    assert torch.equal(rows.float(), ref.to(rdt).float())
