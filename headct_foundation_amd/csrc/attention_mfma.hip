@@ -18,7 +18,7 @@
 
 namespace hct {
 
-int g_attn_bwd3 = 54 + 128;  // bit8 (opt-in, slower): bwd5 for head dim 64 too.   // bit7: long sequences (225 .. 576 tokens) on the five-product one-wave-per-SIMD kernel (bwd5) instead of the two-phase one.   // bit5: the encoder's bwd3 instance is four waves x one key tile (44.7 us) instead of two x two (53.5 us).  bit4: bwd4 as 16 waves x one key tile (128 registers, four waves per SIMD: 287 vs 305 us, -0.09 ms per step) instead of 8 x two.  bit3 (opt-in: measured equal to the kernel it would replace, 116 vs 117 us): persistent forward (fwd4) for head dim 48 with 193 .. 224 tokens.  Which shapes use the key-owner five-product backward: bit0 head dim 48 (<= 256 tokens, bwd3), bit1 head dim 64 (<= 192 tokens, bwd3), bit2 head dim 48 with 193 .. 224 tokens (persistent bwd4)
+int g_attn_bwd3 = 54 + 128 + 1024;  // bit10: the persistent key-owner kernel (bwd4) also for head dim 64 with 129 .. 160 tokens (the ViT-L encoder's 129: 79.6 vs 87.0 us for the two-phase kernel).  bit8 (opt-in, slower): bwd5 for head dim 64 too.   // bit7: long sequences (225 .. 576 tokens) on the five-product one-wave-per-SIMD kernel (bwd5) instead of the two-phase one.   // bit5: the encoder's bwd3 instance is four waves x one key tile (44.7 us) instead of two x two (53.5 us).  bit4: bwd4 as 16 waves x one key tile (128 registers, four waves per SIMD: 287 vs 305 us, -0.09 ms per step) instead of 8 x two.  bit3 (opt-in: measured equal to the kernel it would replace, 116 vs 117 us): persistent forward (fwd4) for head dim 48 with 193 .. 224 tokens.  Which shapes use the key-owner five-product backward: bit0 head dim 48 (<= 256 tokens, bwd3), bit1 head dim 64 (<= 192 tokens, bwd3), bit2 head dim 48 with 193 .. 224 tokens (persistent bwd4)
 int g_attn_dbg = 0;  // timing experiments on the backward kernel: bit0 skip key-owner pass, bit1 skip query-owner pass
 
 namespace {
@@ -1730,6 +1730,16 @@ int attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const fl
                        void* dqkv, hipStream_t s) {
   const int Npad = npad_of(N);
   const int ncu = num_cus_cached();
+  if (!(g_attn_dbg & (4 | 8 | 32)) && (g_attn_bwd3 & 1024) && dh == 64 && Npad == 160) {
+    // (bit 10, default) the persistent key-owner kernel for the ViT-L encoder's 129 tokens at head dim 64: 16 waves x one key tile,
+    // 79.6 us against 87.0 for the two-phase kernel at B * H = 1 536 (scripts/dbg/attn_enc_vitl.py)
+    constexpr size_t l4 = bwd4_lds<64>(160);
+    static_assert(l4 <= (size_t)kMaxLds, "bwd4 LDS (64, 160)");
+    const int nbh = B * H, grid = nbh < ncu ? nbh : ncu;
+    if (int rc = set_lds(attn_bwd4_kernel<64, 160, 1>, l4)) return rc;
+    hipLaunchKernelGGL((attn_bwd4_kernel<64, 160, 1>), dim3(grid), dim3(1024), l4, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, N, H, (bf16*)dqkv, nbh, g_attn_dbg & 0xF80);
+    return check_hip(hipGetLastError(), "attention_bwd4(64,160)");
+  }
   if (!(g_attn_dbg & (4 | 8 | 32)) && (g_attn_bwd3 & 4) && dh == 48 && Npad == 224) {
     // persistent prefetching key-owner kernel, one workgroup per CU: 8 waves x 2 key tiles, 193 .. 224 tokens (the MAE decoder: 217)
     constexpr size_t l4 = bwd4_lds<48>(224);

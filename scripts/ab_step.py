@@ -22,12 +22,12 @@ HOOKS = {
     "attn_bwd1": (lambda: lib.hct_debug_force_simple_attention(14), lambda: lib.hct_debug_force_simple_attention(10)),  # on = single-phase backward
     "attn_bwd4w": (lambda: lib.hct_debug_force_simple_attention(18), lambda: lib.hct_debug_force_simple_attention(10)),  # on = 4-wave two-phase backward
     "fusedfold": (lambda: lib.hct_debug_set_gemm_variant(-7), lambda: lib.hct_debug_set_gemm_variant(-6)),  # on = wgrad splits folded inside the launch
-    "bwd3enc": (lambda: lib.hct_debug_force_simple_attention(100182), lambda: lib.hct_debug_force_simple_attention(100020)),  # on = key-owner backward for the encoder
-    "bwd3k2": (lambda: lib.hct_debug_force_simple_attention(100022), lambda: lib.hct_debug_force_simple_attention(100182)),  # on = encoder backward as two waves x two key tiles
+    "bwd3enc": (lambda: lib.hct_debug_force_simple_attention(101206), lambda: lib.hct_debug_force_simple_attention(100020)),  # on = key-owner backward for the encoder
+    "bwd3k2": (lambda: lib.hct_debug_force_simple_attention(100022), lambda: lib.hct_debug_force_simple_attention(101206)),  # on = encoder backward as two waves x two key tiles
     "bwd3off": (lambda: lib.hct_debug_force_simple_attention(42), lambda: lib.hct_debug_force_simple_attention(10)),  # on = two-phase backward everywhere
-    "bwd4off": (lambda: lib.hct_debug_force_simple_attention(100002), lambda: lib.hct_debug_force_simple_attention(100182)),  # on = two-phase backward for the decoder instead of the persistent key-owner kernel
-    "bwd4k2": (lambda: lib.hct_debug_force_simple_attention(100038), lambda: lib.hct_debug_force_simple_attention(100182)),  # on = bwd4 with 8 waves x two key tiles
-    "fwd4": (lambda: lib.hct_debug_force_simple_attention(100062), lambda: lib.hct_debug_force_simple_attention(100182)),  # on = persistent forward for the decoder
+    "bwd4off": (lambda: lib.hct_debug_force_simple_attention(100002), lambda: lib.hct_debug_force_simple_attention(101206)),  # on = two-phase backward for the decoder instead of the persistent key-owner kernel
+    "bwd4k2": (lambda: lib.hct_debug_force_simple_attention(100038), lambda: lib.hct_debug_force_simple_attention(101206)),  # on = bwd4 with 8 waves x two key tiles
+    "fwd4": (lambda: lib.hct_debug_force_simple_attention(100062), lambda: lib.hct_debug_force_simple_attention(101206)),  # on = persistent forward for the decoder
     "stagger2": (lambda: lib.hct_debug_set_gemm_stagger(2), lambda: lib.hct_debug_set_gemm_stagger(-1)),
     "stagger4": (lambda: lib.hct_debug_set_gemm_stagger(4), lambda: lib.hct_debug_set_gemm_stagger(-1)),
     "skoff": (lambda: lib.hct_debug_set_gemm_variant(-1000 - (1 << 24)), lambda: lib.hct_debug_set_gemm_variant(-1000 - 512)),  # on = whole tiles only (no stream-K remainder round)

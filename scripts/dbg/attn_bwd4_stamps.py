@@ -23,4 +23,4 @@ for extra, nm in ((0, "full"), (0x100, "no main"), (0x200, "no dQ")):
             v = [(rows[(w * 4 + it) * 10 + k] - t0) / 100.0 for k in range(10)]
             print(f"wave {wn} item {it}: " + " ".join(f"{x:7.2f}" for x in v))
 print("columns: " + " | ".join(names))
-lib.hct_debug_force_simple_attention(10); lib.hct_debug_force_simple_attention(100182)
+lib.hct_debug_force_simple_attention(10); lib.hct_debug_force_simple_attention(101206)

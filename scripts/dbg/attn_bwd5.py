@@ -54,5 +54,5 @@ if "time" in sys.argv or len(sys.argv) == 1:
             e1.record(); torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / 5 * 1e3
             print(f"{tag} B={B} N={N} H={H} dh={dh} [{nm}]: {us:8.1f} us  {10.0 * B * H * N * N * dh / us / 1e6:6.1f} TF/s", flush=True)
-lib.hct_debug_force_simple_attention(100000 + 54 + 128)
+lib.hct_debug_force_simple_attention(101206)
 

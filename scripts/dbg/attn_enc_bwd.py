@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from headct_foundation_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda"); st = torch.cuda.current_stream().cuda_stream
-DEFAULT = 100182
+DEFAULT = 101206
 
 
 def bwd(B, N, H, dh, mask, reps=0):

@@ -24,7 +24,7 @@ def fwd(B, N, H, dh, mask, reps=0, seed=0):
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / reps * 1e3
     torch.cuda.synchronize()
-    lib.hct_debug_force_simple_attention(100182)
+    lib.hct_debug_force_simple_attention(101206)
     return o, lse, us
 
 
