@@ -501,6 +501,9 @@ constexpr int kNT = HCT_EPI_CACHE_POLICY;
 #ifndef HCT_EPI_LA_F32
 #define HCT_EPI_LA_F32 1
 #endif
+#ifndef HCT_GELU_VEC8  /* GELU + gelu' of eight elements with the Horner steps of the two 4-vectors interleaved (common.h); 0 = element by element (A/B) */
+#define HCT_GELU_VEC8 1
+#endif
 #ifndef HCT_SLAB_POLICY
 #define HCT_SLAB_POLICY 16  /* cache policy of the wgrad's split-K slab stores: 16 = sc1 write-through (39.83 ms per step), 0 = write-back (39.90), 2 = nt (40.17) */
 #endif
@@ -622,6 +625,11 @@ __device__ __forceinline__ void epilogue_wave64x128_m(const Epilogue& e, const T
         if (MODE == EPI_GELU_BF16) {
           if (e.aux_deriv) {  // aux receives gelu'(pre-activation): the backward then multiplies by it (no second evaluation)
             f32x4 d0, d1;
+#if HCT_GELU_VEC8
+            f32x4 g0, g1;
+            gelu_both8(x0, x1, g0, d0, g1, d1);
+            x0 = g0; x1 = g1;
+#else
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               float ga, da, gb, db;
@@ -629,6 +637,7 @@ __device__ __forceinline__ void epilogue_wave64x128_m(const Epilogue& e, const T
               gelu_both(x1[q], gb, db);
               x0[q] = ga; d0[q] = da; x1[q] = gb; d1[q] = db;
             }
+#endif
             __builtin_amdgcn_raw_buffer_store_b128(pack(d0, d1), tb.aux, vx, sx, kNT);
             HCT_STORE_GUARD();
           } else {
@@ -763,6 +772,11 @@ __device__ __forceinline__ void epilogue_wave64x128_h(const Epilogue& e, const T
         if (MODE == EPI_GELU_BF16) {
           if (e.aux_deriv) {  // aux receives gelu'(pre-activation): the backward then multiplies by it (no second evaluation)
             f32x4 d0, d1;
+#if HCT_GELU_VEC8
+            f32x4 g0, g1;
+            gelu_both8(x0, x1, g0, d0, g1, d1);
+            x0 = g0; x1 = g1;
+#else
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               float ga, da, gb, db;
@@ -770,6 +784,7 @@ __device__ __forceinline__ void epilogue_wave64x128_h(const Epilogue& e, const T
               gelu_both(x1[q], gb, db);
               x0[q] = ga; d0[q] = da; x1[q] = gb; d1[q] = db;
             }
+#endif
             __builtin_amdgcn_raw_buffer_store_b128(pack(d0, d1), tb.aux, vx, sx, kNT);
             HCT_STORE_GUARD();
           } else {
