@@ -27,6 +27,7 @@ static int g_tn_separate_fold = 1;  // 1 = split partials folded by gemm_fold_ke
                                      // DESIGN.md section 5; kept selectable and tested, -6 / -7 of hct_debug_set_gemm_variant)
 static int g_nt_variant = 0;  // 0 auto; 128 / 256 / 4 force one NT kernel (tests cover every instance)
 static int g_w4_small = 0;    // testing (-10 / -11): the two-workgroups-per-CU variant for single-round shapes (tiles < CUs < 2 x tiles)
+static int g_mt3 = 1;         // (-14 / -15: on / off) 192-row tiles for single-round plain / +residual shapes
 static int g_even_rounds = 1; // (-12 / -13: on / off): whole-tile NT launches on ceil(tiles / rounds) workgroups instead of all CUs
 static int g_sk_drop = 0;     // testing (hct_debug_set_gemm_variant(-8 / -9)): stream-K followers publish a wrong sequence number -> every owner times out
 
@@ -709,7 +710,7 @@ __device__ __forceinline__ void tile_bias_halves(const Epilogue& e, int n0, int 
   }
 }
 
-template <int MODE, int STORE_POLICY = kNT>
+template <int MODE, int STORE_POLICY = kNT, int MT = 4>
 __device__ __forceinline__ void epilogue_wave64x128_h(const Epilogue& e, const TileBufs& tb, unsigned char* patch, int lane, int m0,
                                                       int n0, int row0, int col0, int M, int N, const f32x4 (*acc)[8],
                                                       const TileBias (&bias)[2], f32x4 (&cs)[2][2]) {
@@ -746,14 +747,14 @@ __device__ __forceinline__ void epilogue_wave64x128_h(const Epilogue& e, const T
     }
   };
 #pragma unroll
-  for (int s = 0; s < LA; ++s) issue_loads(s);
+  for (int s = 0; s < LA && s < 2 * MT; ++s) issue_loads(s);
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
+  for (int s = 0; s < 2 * MT; ++s) {
     const int i = s >> 1, h = s & 1;
     const bool nok = n0 + col + h * 64 < N;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4*>(patch + frow * 256 + (((jj * 4 + fchk) ^ frow) << 4)) = acc[i][h * 4 + jj];
-    if (s + LA < 8) issue_loads(s + LA);  // LA sub-tiles ahead and BEFORE this sub-tile's stores: waiting for it never drains them
+    if (s + LA < 2 * MT) issue_loads(s + LA);  // LA sub-tiles ahead and BEFORE this sub-tile's stores: waiting for it never drains them
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
       const int pr = it * RB + rr;        // row inside the 16-row patch
@@ -888,7 +889,12 @@ __device__ __forceinline__ uint32_t xcc_id() {  // the XCD (accelerator die) thi
 #ifndef HCT_STAGGER_DMA
 #define HCT_STAGGER_DMA 0
 #endif
-template <int MODE, bool SK = false>
+// MT = row tiles of 16 per wave: 4 (256-row tiles) or 3 (192-row tiles, wave tiles of 48 x 128, for the plain / +residual shapes
+// whose 256-row tiles fill less than one round of CUs while 192-row tiles still fit one: the encoder's M = 14 080, N = 768 GEMMs are 165
+// tiles of 256 rows on 256 CUs and 222 of 192).  The A stage keeps its 16-KiB region and has 12 pieces: waves 6 and 7 issue B pieces
+// only (4 operations per pair instead of 8; their counted wait at the tile top says so).  (Issued as dummies with an out-of-range
+// lane offset instead, the 192-row tiles were only 6 - 10 % faster than the 256-row ones: the main loop pays per DMA INSTRUCTION.)
+template <int MODE, bool SK = false, int MT = 4>
 __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, int K, const bf16* __restrict__ A, int64_t lda,
                                                                  const bf16* __restrict__ B, int64_t ldb, Epilogue e, int ntiles, int stagger,
                                                                  int sk_tiles, int sk_wgs, unsigned char* __restrict__ sk_ws, unsigned sk_seq) {
@@ -903,6 +909,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
 #endif
   constexpr bool kTwoPairs = MODE != EPI_GENERIC && ((HCT_NT_TWO_PAIR_MODES >> MODE) & 1);
   static_assert(!(SK && kTwoPairs), "stream-K items assume one prefetched pair");
+  static_assert(MT == 4 || (MT == 3 && !SK && (MODE == EPI_PLAIN_BF16 || MODE == EPI_RES_F32)), "192-row tiles: whole tiles, plain / +residual epilogues");
   constexpr int kEpiOps = EpiTraits<MODE>::ops_per_tile > 63 ? 63 : EpiTraits<MODE>::ops_per_tile;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ntn = (N + 255) >> 8;
@@ -929,7 +936,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
   // item = (tile id, first K-stage): the operand descriptors are rooted at (m0 | n0, s0 * 32), the stage offsets stay relative
   auto set_tile_id = [&](int id, int s0) {
     const int tm = id / ntn, tn = id - tm * ntn;
-    m0 = tm << 8;
+    m0 = tm * (64 * MT);
     n0 = tn << 8;
     const bf16* Ab = A + (int64_t)m0 * lda + s0 * 32;
     const bf16* Bb = B + (int64_t)n0 * ldb + s0 * 32;
@@ -961,8 +968,10 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
 #ifdef HCT_TIMING_NO_DMA  // diagnostic build: main loop without its operand stream (outputs are garbage)
       asm volatile("" ::"s"(b0 + c * 1024), "s"(b1), "v"(voa[i]), "v"(vob[i]), "s"(kb), "s"(ra), "s"(rb));
 #else
-      dma16s(ra, b0 + c * 1024, voa[i], kb);
-      dma16s(ra, b1 + c * 1024, voa[i], kb + 64);
+      if (MT == 4 || c < 4 * MT) {  // (wave-uniform; 192-row tiles: the A stage has 12 pieces, waves 6 and 7 issue none)
+        dma16s(ra, b0 + c * 1024, voa[i], kb);
+        dma16s(ra, b1 + c * 1024, voa[i], kb + 64);
+      }
       dma16s(rb, b0 + 16384 + c * 1024, vob[i], kb);
       dma16s(rb, b1 + 16384 + c * 1024, vob[i], kb + 64);
 #endif
@@ -973,12 +982,12 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
   //   boundary   : (odd stages only) the next pair has landed (vmcnt + barrier), refill the ring;
   //                issue A' and B-low reads of stage t+1
   //   second half: run the 16 MFMAs of columns 64..127 (B-high) while those reads return
-  f32x4 acc[4][8];
-  bf16x8 b_lo[4], b_hi[4], a0[4], a1[4];
+  f32x4 acc[MT][8];
+  bf16x8 b_lo[4], b_hi[4], a0[MT], a1[MT];
   auto rd_a = [&](int t, bf16x8* af) {
-    const unsigned char* sa = smem + (t % 5) * 32768 + wm * (64 * 64) + foff;
+    const unsigned char* sa = smem + (t % 5) * 32768 + wm * (16 * MT * 64) + foff;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 1024);
+    for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 1024);
   };
   auto rd_b = [&](int t, int half, bf16x8* bq) {
     const unsigned char* sb = smem + (t % 5) * 32768 + 16384 + wn * (128 * 64) + half * 4096 + foff;
@@ -989,7 +998,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
   //  and DMA issue -- 0.55 ms of the 43.8 ms step, scripts/ab_step.py)
   auto mma = [&](int half, const bf16x8* af, const bf16x8* bq) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][half * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[i][half * 4 + j], 0, 0, 0);
@@ -1021,7 +1030,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
 #endif
   constexpr int kTopOps = 8 + EpiTraits<MODE>::ops_per_tile > 63 ? 63 : 8 + EpiTraits<MODE>::ops_per_tile;
   auto land_top = [&](int younger) {  // younger: 0 = nothing issued since pair (0,1), 1 = a specialised epilogue, 2 = a follower's 32 slab stores
-    if (!HCT_NT_COUNTED_TOP || MODE == EPI_GENERIC || younger == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (MT == 3 && wave >= 6) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (these waves issue 4 operations per pair: B pieces only)
+    else if (!HCT_NT_COUNTED_TOP || MODE == EPI_GENERIC || younger == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (younger == 2) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kTopOps) : "memory");
     __builtin_amdgcn_s_barrier();
@@ -1153,7 +1163,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
     const uint32_t item = cit;
     const int cns = SK ? (int)((item >> 18) & 1023) * 2 : nk;  // stages of this item
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
     // nk is even and >= 4 (host dispatch: K % 64 == 0, K >= 128).  Ring of 5 stage buffers; pair (0,1) was issued before
@@ -1267,7 +1277,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
       asm volatile("" : "+v"(ln));  // (not hoisted out of the persistent loop: a register there costs a spill in the main loop)
       const uint32_t off0 = (uint32_t)(wave * 32768 + ln * 16);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, off0 + (uint32_t)((i * 8 + j) * 1024), 0, 16);
@@ -1312,7 +1322,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
           asm volatile("" : "+v"(ln));
           const uint32_t off0 = (uint32_t)(wave * 32768 + ln * 16);
 #pragma unroll
-          for (int i = 0; i < 4; i += 2) {  // 16 loads (16 KiB per wave) in flight: the fragment registers are dead here
+          for (int i = 0; i + 1 < MT; i += 2) {  // 16 loads (16 KiB per wave) in flight: the fragment registers are dead here
             f32x4 v[2][8];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -1335,7 +1345,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
       unsigned char* patch = kTwoPairs ? smem + 4 * 32768 + wave * 4096 : smem + 3 * 32768 + wave * 8192;
       if (MODE == EPI_GENERIC) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) epilogue_tile16x128(e, patch, lane, cm0 + wm * 64 + i * 16, cn0 + wn * 128, M, N, acc[i]);
+        for (int i = 0; i < MT; ++i) epilogue_tile16x128(e, patch, lane, cm0 + wm * (16 * MT) + i * 16, cn0 + wn * 128, M, N, acc[i]);
       } else {
         TileBufs tb;
         const int csz = (MODE == EPI_RES_F32) ? 4 : 2;
@@ -1343,7 +1353,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
         tb.res = tile_rsrc(MODE == EPI_RES_F32 ? (const void*)e.residual : nullptr, e.ldr, 4, cm0, cn0, M, N);
         tb.aux = tile_rsrc((MODE == EPI_GELU_BF16 || MODE == EPI_DGELU_BF16 || MODE == EPI_DGELU_CS) ? e.aux : nullptr, e.ldaux, 2, cm0, cn0, M, N);
         f32x4 cs[2][2] = {{f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}};
-        epilogue_wave64x128_h<MODE, (MODE == EPI_RES_F32 ? HCT_RES_POLICY : kNT)>(e, tb, patch, lane, cm0, cn0, wm * 64, wn * 128, M, N, acc, bh, cs);
+        epilogue_wave64x128_h<MODE, (MODE == EPI_RES_F32 ? HCT_RES_POLICY : kNT), MT>(e, tb, patch, lane, cm0, cn0, wm * (16 * MT), wn * 128, M, N, acc, bh, cs);
         if (MODE == EPI_DGELU_CS) {  // lanes l, l+8, ..., l+56 hold 8 different rows of the same 8 columns
 #pragma unroll
           for (int h = 0; h < 2; ++h)
@@ -2434,6 +2444,7 @@ void hct_debug_set_gemm_variant(int v) {
   if (v == -8 || v == -9) { g_sk_drop = v == -8; return; }
   if (v == -10 || v == -11) { g_w4_small = v == -10; return; }
   if (v == -12 || v == -13) { g_even_rounds = v == -12; return; }
+  if (v == -14 || v == -15) { g_mt3 = v == -14; return; }
   if (v <= -1000) { g_sk_min_k = -v - 1000; return; }       // stream-K of the NT remainder round only for K >= this (huge: off)
   if (v <= -100) { g_sk_gain_pairs = -v - 100; return; }     // ... and only where it saves at least this many stage pairs per CU
   if (v == -6 || v == -7) { g_tn_separate_fold = v == -6; return; }  // -6 / -7: separate fold kernel for the wgrad splits on / off  // -4 / -5: auto-dispatch of the 2-WG/CU variant on / off
@@ -2757,8 +2768,23 @@ int hct_gemm(const hct_gemm_args* a, void* workspace, size_t workspace_bytes, vo
         gsz = (tiles256 + rounds - 1) / rounds;
         gsz = std::min(num_cus(), (gsz + 7) / 8 * 8);  // (a multiple of 8: the tile walk deals ids per XCD)
       }
-      const dim3 grid(sk_tiles ? num_cus() : gsz);
-      ps.tag(a->M, a->N, a->K, fuse_cs ? EPI_DGELU_CS : mode, tiles256, sk_tiles);
+      // 192-row tiles for the plain / +residual shapes whose 256-row tiles fill less than one round of CUs while 192-row tiles still
+      // fit one (the encoder's M = 14 080, N = 768 products: 165 -> 222 tiles, each 3/4 of the work); hct_debug_set_gemm_variant(-14 / -15)
+      const int tiles192 = ((a->M + 191) / 192) * ((a->N + 255) / 256);
+      const bool mt3 = g_mt3 && !sk_tiles && (mode == EPI_PLAIN_BF16 || mode == EPI_RES_F32) && tiles256 < num_cus() && tiles192 <= num_cus() &&
+                       tiles192 > tiles256 && a->M >= 192;
+      const dim3 grid(sk_tiles ? num_cus() : (mt3 ? tiles192 : gsz));
+      ps.tag(a->M, a->N, a->K, fuse_cs ? EPI_DGELU_CS : mode, mt3 ? tiles192 : tiles256, sk_tiles);
+      if (mt3) {
+        if (mode == EPI_PLAIN_BF16)
+          hipLaunchKernelGGL((gemm_bf16_nt256_kernel<EPI_PLAIN_BF16, false, 3>), grid, dim3(512), 0, s, a->M, a->N, a->K, (const bf16*)a->A, a->lda,
+                             (const bf16*)a->B, a->ldb, e, tiles192, 0, 0, 0, (unsigned char*)nullptr, 0u);
+        else
+          hipLaunchKernelGGL((gemm_bf16_nt256_kernel<EPI_RES_F32, false, 3>), grid, dim3(512), 0, s, a->M, a->N, a->K, (const bf16*)a->A, a->lda,
+                             (const bf16*)a->B, a->ldb, e, tiles192, 0, 0, 0, (unsigned char*)nullptr, 0u);
+        HCT_CHECK_LAUNCH("hct_gemm(nt256, 192-row tiles)");
+        return finish_colsum(false);
+      }
       // one start phase = 1/8 of a tile's main loop (nk stages x ~1000 cycles; s_sleep(32) = 2048 cycles); only when each
       // CU runs several tiles (otherwise the delay is pure loss)
       // (a start-phase stagger of the workgroups helped the earlier one-stage-per-step schedule by ~0.1 ms per step; with

@@ -56,6 +56,8 @@ HOOKS = {
     "evenrounds": (lambda: lib.hct_debug_set_gemm_variant(-12), lambda: lib.hct_debug_set_gemm_variant(-13)),
     "skgain12": (lambda: lib.hct_debug_set_gemm_variant(-100 - 12), lambda: lib.hct_debug_set_gemm_variant(-100 - 20)),
     "skgain16": (lambda: lib.hct_debug_set_gemm_variant(-100 - 16), lambda: lib.hct_debug_set_gemm_variant(-100 - 20)),
+    # on = 192-row tiles for the plain / +residual shapes with less than one round of 256-row tiles (the encoder's N = 768 products; the default)
+    "mt3": (lambda: lib.hct_debug_set_gemm_variant(-14), lambda: lib.hct_debug_set_gemm_variant(-15)),
     "none": (lambda: None, lambda: None),
 }
 BWD_RESERVE = 0
