@@ -53,7 +53,8 @@ def _rand(shape, dev, dtype, seed, scale=1.0):
 
 
 @pytest.mark.parametrize("M,N,K", [(55 * 3, 768, 768), (217 * 2, 2304, 768), (130, 3072, 768), (128, 768, 3072),
-                                   (100, 192, 192), (1, 64, 64), (257, 4096, 768), (300, 48, 64)])
+                                   (100, 192, 192), (1, 64, 64), (257, 4096, 768), (300, 48, 64),
+                                   (14080, 768, 768), (1000, 512, 256), (9999, 768, 3072)])  # 192-row tiles (MT = 3): the encoder's shape; ragged last row tiles
 def test_gemm_nt_bf16_mfma(lib, cuda, M, N, K):
     A = _rand((M, K), cuda, torch.bfloat16, 1)
     B = _rand((N, K), cuda, torch.bfloat16, 2, 0.05)
@@ -63,6 +64,13 @@ def test_gemm_nt_bf16_mfma(lib, cuda, M, N, K):
     out = gemm(lib, A, B, 0, 1, M, N, K, bias=bias, residual=res)
     gen = gemm(lib, A, B, 0, 1, M, N, K, bias=bias, residual=res, force_generic=True)
     assert rel_err(out, ref) < 1e-5 and rel_err(gen, ref) < 1e-5  # exact bf16 products, fp32 accumulate
+    # the default dispatch takes 192-row tiles where 256-row tiles fill less than one round of CUs; -15 switches them off: bit-equal
+    lib.hct_debug_set_gemm_variant(-15)
+    try:
+        o256 = gemm(lib, A, B, 0, 1, M, N, K, bias=bias, residual=res)
+    finally:
+        lib.hct_debug_set_gemm_variant(-14)
+    assert torch.equal(o256, out)
     for variant in (128, 256, 4):  # every tuned NT kernel (2-stage 128^2, persistent 256^2, 2-WG/CU 256x128)
         lib.hct_debug_set_gemm_variant(variant)
         try:
