@@ -916,10 +916,16 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
   float* const colsum_out = e.colsum_partial;  // by value: indexing through `e` made hipcc keep a copy of the struct in scratch
 
   // staging: 1 KiB piece = 16 rows x 64 B; wave w moves pieces 2w, 2w+1 of A and of B each stage
-  uint32_t voa[2], vob[2];
+  // HCT_NT_LOADER_WAVES=1 (experiment): waves 0 .. 3 -- one per SIMD -- move ALL the pieces (4 of A and 4 of B each), so that on every
+  // SIMD the wave that is held by its DMA issues has a partner that only multiplies
+#ifndef HCT_NT_LOADER_WAVES
+#define HCT_NT_LOADER_WAVES 0
+#endif
+  constexpr int NP = HCT_NT_LOADER_WAVES ? 4 : 2;  // pieces of each operand per loading wave and stage
+  uint32_t voa[NP], vob[NP];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (wave * 2 + i) * 16 + (lane >> 2);
+  for (int i = 0; i < NP; ++i) {
+    const int row = ((wave & (HCT_NT_LOADER_WAVES ? 3 : 7)) * NP + i) * 16 + (lane >> 2);
     const int src_chunk = (lane & 3) ^ swz64(row);
     voa[i] = (uint32_t)(row * lda * 2 + src_chunk * 16);
     vob[i] = (uint32_t)(row * ldb * 2 + src_chunk * 16);
@@ -959,9 +965,10 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
   auto stage_pair = [&](int t) {
     const uint32_t b0 = lds0 + (t % 5) * 32768, b1 = lds0 + ((t + 1) % 5) * 32768;  // wave-uniform: SALU only
     const uint32_t kb = (uint32_t)t * 64;                                            // 32 bf16 = 64 B per stage
+    if (HCT_NT_LOADER_WAVES && wave >= 4) return;  // (wave-uniform)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = wave * 2 + i;
+    for (int i = 0; i < NP; ++i) {
+      const int c = wave * NP + i;
       // the stage's K offset rides in the scalar soffset operand: the lane offsets stay tile- and stage-invariant (no
       // per-stage VALU, nothing for the compiler to pre-compute and spill); rows past M are still dropped by the
       // descriptor's range check on voffset
@@ -1030,6 +1037,13 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_nt256_kernel(int M, int N, i
 #endif
   constexpr int kTopOps = 8 + EpiTraits<MODE>::ops_per_tile > 63 ? 63 : 8 + EpiTraits<MODE>::ops_per_tile;
   auto land_top = [&](int younger) {  // younger: 0 = nothing issued since pair (0,1), 1 = a specialised epilogue, 2 = a follower's 32 slab stores
+#if HCT_NT_LOADER_WAVES  // operations per pair: 16 on the loading waves (8 where a 192-row tile leaves the wave B pieces only), none on the others
+    if (wave >= 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (MT == 3 && wave == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    return;
+#endif
     if (MT == 3 && wave >= 6) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (these waves issue 4 operations per pair: B pieces only)
     else if (!HCT_NT_COUNTED_TOP || MODE == EPI_GENERIC || younger == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (younger == 2) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
